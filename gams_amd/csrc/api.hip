@@ -1,0 +1,147 @@
+// api.hip -- handle, timers and HBM-resident ctg sequences of libgams_gpu.
+
+#include "common.hpp"
+
+extern "C" {
+
+int gams_gpu_create(int device, gams_gpu_t **out) {
+    if (!out) return GAMS_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return GAMS_ENODEV;
+    if (device < 0 || device >= n) return GAMS_ENODEV;
+    gams_gpu_t *h = new gams_gpu_t();
+    h->device = device;
+    auto bail = [&](hipError_t e, const char *what) {
+        fprintf(stderr, "gams_gpu_create: %s: %s\n", what, hipGetErrorString(e));
+        gams_gpu_destroy(h);
+        return GAMS_EHIP;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
+    h->cus = prop.multiProcessorCount;
+    h->hbm = prop.totalGlobalMem;
+    snprintf(h->arch, sizeof h->arch, "%s", prop.gcnArchName);
+    if ((e = hipStreamCreateWithFlags(&h->compute, hipStreamNonBlocking)) != hipSuccess)
+        return bail(e, "hipStreamCreate(compute)");
+    if ((e = hipStreamCreateWithFlags(&h->copy, hipStreamNonBlocking)) != hipSuccess)
+        return bail(e, "hipStreamCreate(copy)");
+    if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
+    *out = h;
+    return GAMS_OK;
+}
+
+void gams_gpu_destroy(gams_gpu_t *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->compute) {
+        (void)hipStreamSynchronize(h->compute);
+        (void)hipStreamDestroy(h->compute);
+    }
+    if (h->copy) {
+        (void)hipStreamSynchronize(h->copy);
+        (void)hipStreamDestroy(h->copy);
+    }
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+}
+
+const char *gams_gpu_last_error(gams_gpu_t *h) { return h ? h->err.c_str() : "null handle"; }
+
+int gams_gpu_device_info(gams_gpu_t *h, char *arch, size_t arch_len, int32_t *compute_units,
+                         uint64_t *hbm_bytes) {
+    if (!h) return GAMS_EINVAL;
+    if (arch && arch_len) snprintf(arch, arch_len, "%s", h->arch);
+    if (compute_units) *compute_units = h->cus;
+    if (hbm_bytes) *hbm_bytes = h->hbm;
+    return GAMS_OK;
+}
+
+int gams_gpu_sync(gams_gpu_t *h) {
+    if (!h) return GAMS_EINVAL;
+    GAMS_HIP(h, hipSetDevice(h->device));
+    GAMS_HIP(h, hipStreamSynchronize(h->copy));
+    GAMS_HIP(h, hipStreamSynchronize(h->compute));
+    return GAMS_OK;
+}
+
+int gams_gpu_timer_start(gams_gpu_t *h) {
+    if (!h) return GAMS_EINVAL;
+    GAMS_HIP(h, hipSetDevice(h->device));
+    GAMS_HIP(h, hipEventRecord(h->ev0, h->compute));
+    return GAMS_OK;
+}
+
+int gams_gpu_timer_stop(gams_gpu_t *h, float *ms) {
+    if (!h || !ms) return gams_fail(h, GAMS_EINVAL, "timer_stop: null argument");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    GAMS_HIP(h, hipEventRecord(h->ev1, h->compute));
+    GAMS_HIP(h, hipEventSynchronize(h->ev1));
+    GAMS_HIP(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return GAMS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// seqset: the batch of gunzipped `seq:{ctg}` values, 1 B/base, in one HBM buffer
+// ---------------------------------------------------------------------------
+int gams_seqset_create(gams_gpu_t *h, uint32_t n_ctg, const uint32_t *lengths, gams_seqset_t **out) {
+    if (!h || !out || (n_ctg && !lengths)) return gams_fail(h, GAMS_EINVAL, "seqset_create: null argument");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    gams_seqset_t *s = new gams_seqset_t();
+    s->n_ctg = n_ctg;
+    s->len.assign(lengths, lengths + n_ctg);
+    s->off.resize(n_ctg);
+    uint64_t o = 0;
+    for (uint32_t i = 0; i < n_ctg; ++i) {
+        s->off[i] = o;
+        o += ((uint64_t)lengths[i] + 255u) & ~(uint64_t)255u;  // next ctg on a 256-B boundary
+    }
+    s->bytes = o + 256;  // tail slack: kernels read whole 16-B chunks
+    hipError_t e = hipMalloc(&s->d_seq, s->bytes);
+    if (e != hipSuccess) {
+        delete s;
+        return gams_fail(h, e == hipErrorOutOfMemory ? GAMS_ENOMEM : GAMS_EHIP,
+                         std::string("seqset_create: hipMalloc: ") + hipGetErrorString(e));
+    }
+    // padding bytes are never counted, but keep them defined
+    e = hipMemsetAsync(s->d_seq, 0, s->bytes, h->copy);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->copy);
+    if (e != hipSuccess) {
+        (void)hipFree(s->d_seq);
+        delete s;
+        return gams_fail(h, GAMS_EHIP, std::string("seqset_create: memset: ") + hipGetErrorString(e));
+    }
+    *out = s;
+    return GAMS_OK;
+}
+
+int gams_seqset_upload(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, const uint8_t *seq) {
+    if (!h || !s || !seq) return gams_fail(h, GAMS_EINVAL, "seqset_upload: null argument");
+    if (i >= s->n_ctg) return gams_fail(h, GAMS_EINVAL, "seqset_upload: ctg index out of range");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    if (s->len[i] == 0) return GAMS_OK;
+    if (s->gcindex) {
+        GAMS_HIP(h, hipStreamSynchronize(h->compute));
+        gams_seqset_gcindex_free(s);  // the bytes it indexed are about to change
+    }
+    GAMS_HIP(h, hipMemcpyAsync(s->d_seq + s->off[i], seq, s->len[i], hipMemcpyHostToDevice, h->copy));
+    GAMS_HIP(h, hipStreamSynchronize(h->copy));
+    return GAMS_OK;
+}
+
+void gams_seqset_destroy(gams_gpu_t *h, gams_seqset_t *s) {
+    if (!s) return;
+    if (h) {
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->compute);
+    }
+    gams_seqset_gcindex_free(s);
+    (void)hipFree(s->d_seq);
+    delete s;
+}
+
+}  // extern "C"

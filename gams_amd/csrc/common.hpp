@@ -1,0 +1,99 @@
+// common.hpp -- shared host/device plumbing of libgams_gpu (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gams_gpu.h"
+
+struct gams_gpu {
+    int device = 0;
+    hipStream_t compute = nullptr;  // every kernel of the library runs here
+    hipStream_t copy = nullptr;     // H2D staging of seq: bytes
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int cus = 0;
+    uint64_t hbm = 0;
+    char arch[64] = {0};
+    std::string err;
+};
+
+inline int gams_fail(gams_gpu_t *h, int code, const std::string &msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+#define GAMS_HIP(h, call)                                                           \
+    do {                                                                            \
+        hipError_t e_ = (call);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            return gams_fail((h), GAMS_EHIP,                                        \
+                             std::string(#call) + ": " + hipGetErrorString(e_));    \
+        }                                                                           \
+    } while (0)
+
+struct gams_gcindex;  // sw.hip: prefix index over the seqset buffer
+
+struct gams_seqset {
+    uint32_t n_ctg = 0;
+    std::vector<uint32_t> len;      // bases per ctg
+    std::vector<uint64_t> off;      // byte offset of ctg i inside d_seq (256-B aligned)
+    uint64_t bytes = 0;             // allocation size (with tail slack for 16-B over-reads)
+    uint8_t *d_seq = nullptr;
+    gams_gcindex *gcindex = nullptr;  // built lazily by gams_gpu_sw, dropped by every upload
+};
+
+int gams_seqset_gcindex(gams_gpu_t *h, gams_seqset_t *s);
+void gams_seqset_gcindex_free(gams_seqset_t *s);
+
+// ---------------------------------------------------------------------------
+// wave64 / workgroup scan primitives (device)
+// ---------------------------------------------------------------------------
+// Inclusive add-scan across the 64 lanes of a wavefront with DPP row shifts and
+// the GFX9 row broadcasts: 6 VALU adds, no LDS traffic.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+    return (uint32_t)v;
+}
+
+// 64-bit variant (only the wide z-score path needs it): shuffle based.
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t x) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t lo = __shfl_up((uint32_t)x, d, 64);
+        uint32_t hi = __shfl_up((uint32_t)(x >> 32), d, 64);
+        uint64_t y = ((uint64_t)hi << 32) | lo;
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) { return wave_incl_scan_u32(x); }
+__device__ __forceinline__ uint64_t wave_incl_scan(uint64_t x) { return wave_incl_scan_u64(x); }
+
+// Exclusive scan over a 256-thread workgroup (4 waves).  `ws` is LDS scratch of
+// 4 elements; the call contains two barriers and may be used back to back.
+template <typename T>
+__device__ __forceinline__ T block_excl_scan_256(T v, T *ws, T &total) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    T inc = wave_incl_scan(v);
+    if (lane == 63) ws[wv] = inc;
+    __syncthreads();
+    T w0 = ws[0], w1 = ws[1], w2 = ws[2], w3 = ws[3];
+    __syncthreads();
+    T base = (wv > 0 ? w0 : (T)0) + (wv > 1 ? w1 : (T)0) + (wv > 2 ? w2 : (T)0);
+    total = w0 + w1 + w2 + w3;
+    return base + inc - v;
+}
+

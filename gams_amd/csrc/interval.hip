@@ -1,0 +1,366 @@
+// interval.hip -- sorted-interval binary-search kernels replacing the rust_lapper
+// `idx:` index and the IntSpan intersections of `anno`.
+//
+//   interval_count_kernel   gams::count_rg  (src/libs/utils.rs:24-36) = Lapper::count:
+//       #{start < qe} - #{stop <= qs} by two lower bounds over the group's
+//       independently sorted starts[] and stops[] (rust-lapper 1.1.0, BITS).
+//   interval_locate_kernel  gams::find_one_idx (src/libs/utils.rs:7-22) =
+//       Lapper::find(qs,qe).next(): first interval in (start,stop) order with
+//       start < qe && stop > qs; the scan begins at lower_bound(qs - max_len)
+//       exactly like the crate's iterator and stops at start >= qe.
+//   span_cover_kernel       anno (src/cmd_gams/anno.rs:128-139):
+//       |set[chr] & [ctg] & [range]| / |range| from a prefix of covered bases
+//       over the chr's sorted disjoint spans (two upper bounds per query).
+//
+// Intervals are half-open [start, stop) with stop = end+1 as the reference
+// stores them (src/libs/redis.rs:245-248, 291-294); queries are passed the way
+// the reference passes them: (rg.start, rg.end), i.e. the end is exclusive.
+// One lane per query; 16 B/query of traffic plus the probed table lines.
+
+#include "common.hpp"
+
+#include <algorithm>
+#include <numeric>
+
+struct gams_index {
+    uint32_t n_groups = 0;
+    uint64_t m = 0;
+    uint64_t *d_off = nullptr;       // n_groups+1
+    uint32_t *d_starts = nullptr;    // per group, ascending (for count)
+    uint32_t *d_stops = nullptr;     // per group, ascending, sorted independently (for count)
+    uint32_t *d_lstart = nullptr;    // per group, (start,stop)-sorted pairs (for locate)
+    uint32_t *d_lstop = nullptr;
+    uint64_t *d_lorig = nullptr;     // caller's index of each sorted pair
+    uint32_t *d_maxlen = nullptr;    // per group: max(stop - start)
+};
+
+struct gams_spans {
+    uint32_t n_groups = 0;
+    uint64_t m = 0;
+    uint64_t *d_off = nullptr;
+    int32_t *d_lo = nullptr, *d_hi = nullptr;
+    uint64_t *d_cum = nullptr;       // covered bases in the group's spans before span i
+};
+
+namespace {
+
+// first index in [lo,hi) whose value is >= key (number of elements < key, offset by lo)
+__device__ __forceinline__ uint64_t lower_bound_u32(const uint32_t *a, uint64_t lo, uint64_t hi, uint64_t key) {
+    while (lo < hi) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if ((uint64_t)a[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void interval_count_kernel(const uint64_t *off, const uint32_t *starts,
+                                                             const uint32_t *stops, uint32_t n_groups,
+                                                             const uint32_t *group, const uint32_t *qs,
+                                                             const uint32_t *qe, uint64_t nq, int32_t *out) {
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const uint32_t g = group[q];
+    if (g >= n_groups) {  // utils.rs:29-32: ctg not in the index -> 0
+        out[q] = 0;
+        return;
+    }
+    const uint64_t lo = off[g], hi = off[g + 1];
+    // Lapper::count: first = bsearch_seq(start + 1, stops); last = bsearch_seq(stop, starts)
+    const uint64_t first = lower_bound_u32(stops, lo, hi, (uint64_t)qs[q] + 1u) - lo;
+    const uint64_t last = lower_bound_u32(starts, lo, hi, (uint64_t)qe[q]) - lo;
+    out[q] = (int32_t)((int64_t)last - (int64_t)first);
+}
+
+__global__ __launch_bounds__(256) void interval_locate_kernel(const uint64_t *off, const uint32_t *lstart,
+                                                              const uint32_t *lstop, const uint64_t *lorig,
+                                                              const uint32_t *maxlen, uint32_t n_groups,
+                                                              const uint32_t *group, const uint32_t *qs,
+                                                              const uint32_t *qe, uint64_t nq, int64_t *out) {
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const uint32_t g = group[q];
+    int64_t hit = -1;
+    if (g < n_groups) {
+        const uint64_t lo = off[g], hi = off[g + 1];
+        const uint32_t s = qs[q], e = qe[q];
+        const uint32_t ml = maxlen[g];
+        const uint32_t from = s > ml ? s - ml : 0u;  // checked_sub(max_len).unwrap_or(0)
+        // Lapper::lower_bound: first interval whose start >= from
+        for (uint64_t i = lower_bound_u32(lstart, lo, hi, from); i < hi; ++i) {
+            const uint32_t is = lstart[i];
+            if (is < e && lstop[i] > s) {  // Interval::overlap
+                hit = (int64_t)lorig[i];
+                break;
+            }
+            if (is >= e) break;
+        }
+    }
+    out[q] = hit;
+}
+
+// number of spans in [lo,hi) with span_lo <= x
+__device__ __forceinline__ uint64_t upper_bound_i32(const int32_t *a, uint64_t lo, uint64_t hi, int32_t x) {
+    while (lo < hi) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (a[mid] <= x)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// covered positions <= x inside the group's spans
+__device__ __forceinline__ uint64_t covered_upto(const int32_t *slo, const int32_t *shi, const uint64_t *cum,
+                                                 uint64_t lo, uint64_t hi, int32_t x) {
+    const uint64_t i = upper_bound_i32(slo, lo, hi, x);
+    if (i == lo) return 0;
+    const int32_t top = shi[i - 1] < x ? shi[i - 1] : x;
+    return cum[i - 1] + (uint64_t)((int64_t)top - slo[i - 1] + 1);
+}
+
+__global__ __launch_bounds__(256) void span_cover_kernel(const uint64_t *off, const int32_t *slo,
+                                                         const int32_t *shi, const uint64_t *cum,
+                                                         uint32_t n_groups, const uint32_t *group,
+                                                         const int32_t *clip_lo, const int32_t *clip_hi,
+                                                         const int32_t *qs, const int32_t *qe, uint64_t nq,
+                                                         float *out) {
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const uint32_t g = group[q];
+    const int32_t s = qs[q], e = qe[q];
+    float prop = 0.0f;  // anno.rs:128: chr absent from the set
+    if (g < n_groups && e >= s) {
+        const int32_t L = s > clip_lo[q] ? s : clip_lo[q];
+        const int32_t H = e < clip_hi[q] ? e : clip_hi[q];
+        uint64_t card = 0;
+        if (H >= L) {
+            const uint64_t lo = off[g], hi = off[g + 1];
+            const uint64_t upto_h = covered_upto(slo, shi, cum, lo, hi, H);
+            const uint64_t upto_l = L > INT32_MIN ? covered_upto(slo, shi, cum, lo, hi, L - 1) : 0;
+            card = upto_h - upto_l;
+        }
+        const int32_t total = (int32_t)((int64_t)e - s + 1);
+        prop = (float)(int32_t)card / (float)total;  // cardinality() as f32 / cardinality() as f32
+    }
+    out[q] = prop;
+}
+
+template <typename T>
+hipError_t to_device(T **d, const T *hsrc, size_t n) {
+    hipError_t e = hipMalloc(d, std::max<size_t>(n, 1) * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (n) e = hipMemcpy(*d, hsrc, n * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+}
+
+// scratch device copies of the query columns + result column
+struct QueryBuf {
+    std::vector<void *> ptrs;
+    ~QueryBuf() {
+        for (void *p : ptrs) (void)hipFree(p);
+    }
+    template <typename T>
+    hipError_t in(T **d, const T *hsrc, uint64_t n, hipStream_t st) {
+        hipError_t e = hipMalloc(d, std::max<uint64_t>(n, 1) * sizeof(T));
+        if (e != hipSuccess) return e;
+        ptrs.push_back(*d);
+        if (n && hsrc) e = hipMemcpyAsync(*d, hsrc, n * sizeof(T), hipMemcpyHostToDevice, st);
+        return e;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int gams_index_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_off, const uint32_t *starts,
+                      const uint32_t *stops, gams_index_t **out) {
+    if (!h || !out || !group_off) return gams_fail(h, GAMS_EINVAL, "index_create: null argument");
+    const uint64_t m = group_off[n_groups];
+    if (m && (!starts || !stops)) return gams_fail(h, GAMS_EINVAL, "index_create: null interval arrays");
+    for (uint32_t g = 0; g < n_groups; ++g)
+        if (group_off[g] > group_off[g + 1]) return gams_fail(h, GAMS_EINVAL, "index_create: group_off not ascending");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    // Lapper::new: intervals.sort() by (start, stop); starts and stops also sorted on their own
+    std::vector<uint32_t> ss(starts, starts + m), tt(stops, stops + m), ls(m), lt(m), maxlen(n_groups, 0);
+    std::vector<uint64_t> perm(m);
+    std::iota(perm.begin(), perm.end(), 0ull);
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const uint64_t lo = group_off[g], hi = group_off[g + 1];
+        std::sort(ss.begin() + lo, ss.begin() + hi);
+        std::sort(tt.begin() + lo, tt.begin() + hi);
+        std::stable_sort(perm.begin() + lo, perm.begin() + hi, [&](uint64_t a, uint64_t b) {
+            return starts[a] != starts[b] ? starts[a] < starts[b] : stops[a] < stops[b];
+        });
+        uint32_t ml = 0;
+        for (uint64_t i = lo; i < hi; ++i) {
+            ls[i] = starts[perm[i]];
+            lt[i] = stops[perm[i]];
+            if (lt[i] > ls[i]) ml = std::max(ml, lt[i] - ls[i]);
+        }
+        maxlen[g] = ml;
+    }
+    gams_index_t *ix = new gams_index_t();
+    ix->n_groups = n_groups;
+    ix->m = m;
+    hipError_t e = to_device(&ix->d_off, group_off, (size_t)n_groups + 1);
+    if (e == hipSuccess) e = to_device(&ix->d_starts, ss.data(), m);
+    if (e == hipSuccess) e = to_device(&ix->d_stops, tt.data(), m);
+    if (e == hipSuccess) e = to_device(&ix->d_lstart, ls.data(), m);
+    if (e == hipSuccess) e = to_device(&ix->d_lstop, lt.data(), m);
+    if (e == hipSuccess) e = to_device(&ix->d_lorig, perm.data(), m);
+    if (e == hipSuccess) e = to_device(&ix->d_maxlen, maxlen.data(), n_groups);
+    if (e != hipSuccess) {
+        gams_index_destroy(h, ix);
+        return gams_fail(h, e == hipErrorOutOfMemory ? GAMS_ENOMEM : GAMS_EHIP,
+                         std::string("index_create: ") + hipGetErrorString(e));
+    }
+    *out = ix;
+    return GAMS_OK;
+}
+
+void gams_index_destroy(gams_gpu_t *h, gams_index_t *ix) {
+    if (!ix) return;
+    if (h) {
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->compute);
+    }
+    (void)hipFree(ix->d_off);
+    (void)hipFree(ix->d_starts);
+    (void)hipFree(ix->d_stops);
+    (void)hipFree(ix->d_lstart);
+    (void)hipFree(ix->d_lstop);
+    (void)hipFree(ix->d_lorig);
+    (void)hipFree(ix->d_maxlen);
+    delete ix;
+}
+
+#define Q_HIP(call)                                                                            \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return gams_fail(h, GAMS_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int gams_gpu_count(gams_gpu_t *h, gams_index_t *ix, const uint32_t *group, const uint32_t *qs,
+                   const uint32_t *qe, uint64_t nq, int32_t *count) {
+    if (!h || !ix || (nq && (!group || !qs || !qe || !count)))
+        return gams_fail(h, GAMS_EINVAL, "gpu_count: null argument");
+    if (nq == 0) return GAMS_OK;
+    if ((nq + 255) / 256 > 0x7fffffffull) return gams_fail(h, GAMS_EUNSUPPORTED, "gpu_count: too many queries");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    QueryBuf qb;
+    uint32_t *d_g, *d_s, *d_e;
+    int32_t *d_o;
+    Q_HIP(qb.in(&d_g, group, nq, h->compute));
+    Q_HIP(qb.in(&d_s, qs, nq, h->compute));
+    Q_HIP(qb.in(&d_e, qe, nq, h->compute));
+    Q_HIP(qb.in(&d_o, (const int32_t *)nullptr, nq, h->compute));
+    hipLaunchKernelGGL(interval_count_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->compute,
+                       ix->d_off, ix->d_starts, ix->d_stops, ix->n_groups, d_g, d_s, d_e, nq, d_o);
+    Q_HIP(hipGetLastError());
+    Q_HIP(hipMemcpyAsync(count, d_o, nq * sizeof(int32_t), hipMemcpyDeviceToHost, h->compute));
+    Q_HIP(hipStreamSynchronize(h->compute));
+    return GAMS_OK;
+}
+
+int gams_gpu_locate(gams_gpu_t *h, gams_index_t *ix, const uint32_t *group, const uint32_t *qs,
+                    const uint32_t *qe, uint64_t nq, int64_t *hit) {
+    if (!h || !ix || (nq && (!group || !qs || !qe || !hit)))
+        return gams_fail(h, GAMS_EINVAL, "gpu_locate: null argument");
+    if (nq == 0) return GAMS_OK;
+    if ((nq + 255) / 256 > 0x7fffffffull) return gams_fail(h, GAMS_EUNSUPPORTED, "gpu_locate: too many queries");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    QueryBuf qb;
+    uint32_t *d_g, *d_s, *d_e;
+    int64_t *d_o;
+    Q_HIP(qb.in(&d_g, group, nq, h->compute));
+    Q_HIP(qb.in(&d_s, qs, nq, h->compute));
+    Q_HIP(qb.in(&d_e, qe, nq, h->compute));
+    Q_HIP(qb.in(&d_o, (const int64_t *)nullptr, nq, h->compute));
+    hipLaunchKernelGGL(interval_locate_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->compute,
+                       ix->d_off, ix->d_lstart, ix->d_lstop, ix->d_lorig, ix->d_maxlen, ix->n_groups, d_g, d_s,
+                       d_e, nq, d_o);
+    Q_HIP(hipGetLastError());
+    Q_HIP(hipMemcpyAsync(hit, d_o, nq * sizeof(int64_t), hipMemcpyDeviceToHost, h->compute));
+    Q_HIP(hipStreamSynchronize(h->compute));
+    return GAMS_OK;
+}
+
+int gams_spans_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_off, const int32_t *lo,
+                      const int32_t *hi, gams_spans_t **out) {
+    if (!h || !out || !group_off) return gams_fail(h, GAMS_EINVAL, "spans_create: null argument");
+    const uint64_t m = group_off[n_groups];
+    if (m && (!lo || !hi)) return gams_fail(h, GAMS_EINVAL, "spans_create: null span arrays");
+    std::vector<uint64_t> cum(m);
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        if (group_off[g] > group_off[g + 1]) return gams_fail(h, GAMS_EINVAL, "spans_create: group_off not ascending");
+        uint64_t c = 0;
+        for (uint64_t i = group_off[g]; i < group_off[g + 1]; ++i) {
+            if (hi[i] < lo[i] || (i > group_off[g] && lo[i] <= hi[i - 1]))
+                return gams_fail(h, GAMS_EINVAL, "spans_create: spans must be sorted and disjoint");
+            cum[i] = c;
+            c += (uint64_t)((int64_t)hi[i] - lo[i] + 1);
+        }
+    }
+    GAMS_HIP(h, hipSetDevice(h->device));
+    gams_spans_t *sp = new gams_spans_t();
+    sp->n_groups = n_groups;
+    sp->m = m;
+    hipError_t e = to_device(&sp->d_off, group_off, (size_t)n_groups + 1);
+    if (e == hipSuccess) e = to_device(&sp->d_lo, lo, m);
+    if (e == hipSuccess) e = to_device(&sp->d_hi, hi, m);
+    if (e == hipSuccess) e = to_device(&sp->d_cum, cum.data(), m);
+    if (e != hipSuccess) {
+        gams_spans_destroy(h, sp);
+        return gams_fail(h, e == hipErrorOutOfMemory ? GAMS_ENOMEM : GAMS_EHIP,
+                         std::string("spans_create: ") + hipGetErrorString(e));
+    }
+    *out = sp;
+    return GAMS_OK;
+}
+
+void gams_spans_destroy(gams_gpu_t *h, gams_spans_t *sp) {
+    if (!sp) return;
+    if (h) {
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->compute);
+    }
+    (void)hipFree(sp->d_off);
+    (void)hipFree(sp->d_lo);
+    (void)hipFree(sp->d_hi);
+    (void)hipFree(sp->d_cum);
+    delete sp;
+}
+
+int gams_gpu_cover(gams_gpu_t *h, gams_spans_t *sp, const uint32_t *group, const int32_t *clip_lo,
+                   const int32_t *clip_hi, const int32_t *qs, const int32_t *qe, uint64_t nq, float *prop) {
+    if (!h || !sp || (nq && (!group || !clip_lo || !clip_hi || !qs || !qe || !prop)))
+        return gams_fail(h, GAMS_EINVAL, "gpu_cover: null argument");
+    if (nq == 0) return GAMS_OK;
+    if ((nq + 255) / 256 > 0x7fffffffull) return gams_fail(h, GAMS_EUNSUPPORTED, "gpu_cover: too many queries");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    QueryBuf qb;
+    uint32_t *d_g;
+    int32_t *d_cl, *d_ch, *d_s, *d_e;
+    float *d_o;
+    Q_HIP(qb.in(&d_g, group, nq, h->compute));
+    Q_HIP(qb.in(&d_cl, clip_lo, nq, h->compute));
+    Q_HIP(qb.in(&d_ch, clip_hi, nq, h->compute));
+    Q_HIP(qb.in(&d_s, qs, nq, h->compute));
+    Q_HIP(qb.in(&d_e, qe, nq, h->compute));
+    Q_HIP(qb.in(&d_o, (const float *)nullptr, nq, h->compute));
+    hipLaunchKernelGGL(span_cover_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->compute,
+                       sp->d_off, sp->d_lo, sp->d_hi, sp->d_cum, sp->n_groups, d_g, d_cl, d_ch, d_s, d_e, nq,
+                       d_o);
+    Q_HIP(hipGetLastError());
+    Q_HIP(hipMemcpyAsync(prop, d_o, nq * sizeof(float), hipMemcpyDeviceToHost, h->compute));
+    Q_HIP(hipStreamSynchronize(h->compute));
+    return GAMS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,368 @@
+// sw.hip -- windows around features: center_sw geometry + range GC + flank statistics.
+//
+// Replaces, per feature of one ctg (src/cmd_gams/sw.rs:141-184):
+//   gams::center_sw         src/libs/window.rs:3-56
+//   gams::cache_gc_content  src/libs/utils.rs:141-162   (round4 on return)
+//   gams::center_resize     src/libs/window.rs:96-124
+//   gams::cache_gc_stat     src/libs/utils.rs:189-213 -> gc_stat utils.rs:164-187
+//
+// GC of an arbitrary range comes from a prefix index over the whole seqset
+// buffer, built once per seqset by two kernels:
+//   gc_index_build  one workgroup per 64 KiB segment: 16-bit G/C mask per 16-B
+//                   chunk + segment-local prefix (same layout as the wave tile)
+//   gc_index_scan   exclusive scan of the segment totals (u64)
+// P(y) = seg_base[y >> 16] + (PM[y >> 4] >> 16) + popcount(PM[y >> 4] & low(y & 15))
+// and gc_count(range) = P(end+1) - P(start): 6 loads per range (4 B + 8 B each side).
+// The parent is a single span, so IntSpan index/slice/at are plain arithmetic.
+// Statistics are evaluated in the reference's f32 order (-ffp-contract=off).
+
+#include "common.hpp"
+
+#include <algorithm>
+
+struct gams_gcindex {
+    uint32_t *d_pm = nullptr;        // per 16-B chunk: local prefix << 16 | mask
+    uint64_t *d_seg = nullptr;       // per 64 KiB segment: GC count before it
+    uint64_t n_chunks = 0, n_segs = 0;
+};
+
+namespace {
+
+__device__ __forceinline__ uint32_t gc_nibble(uint32_t x) {
+    uint32_t y = (x & 0xDBDBDBDBu) ^ 0x43434343u;
+    uint32_t t = (y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    uint32_t f = ~(t | y) & 0x80808080u;
+    uint32_t g = f | (f >> 7);
+    g |= g >> 14;
+    return (g >> 7) & 0xFu;
+}
+
+// one workgroup (256 threads) per segment of 4096 chunks = 64 KiB
+__global__ __launch_bounds__(256) void gc_index_build(const uint8_t *seq, uint64_t n_chunks, uint32_t *pm,
+                                                       uint64_t *seg_tot) {
+    __shared__ uint32_t ws[4];
+    __shared__ uint32_t msk[4096 + 16];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t c0 = (uint64_t)blockIdx.x * 4096u;
+    const uint4 *src = reinterpret_cast<const uint4 *>(seq);
+    // coalesced: in trip q the workgroup reads 256 consecutive chunks (4 KiB)
+#pragma unroll 4
+    for (uint32_t q = 0; q < 16; ++q) {
+        const uint32_t lc = q * 256u + tid;
+        const uint64_t c = c0 + lc;
+        uint32_t m = 0;
+        if (c < n_chunks) {
+            const uint4 v = src[c];
+            m = gc_nibble(v.x) | (gc_nibble(v.y) << 4) | (gc_nibble(v.z) << 8) | (gc_nibble(v.w) << 12);
+        }
+        msk[lc + (lc >> 8)] = m;  // +1 word per 256: thread t's 16-word run starts on bank 17t
+    }
+    __syncthreads();
+    // thread t owns chunks [16t, 16t+16) of the segment
+    uint32_t s = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 16; ++q) {
+        const uint32_t lc = tid * 16u + q;
+        s += __popc(msk[lc + (lc >> 8)]);
+    }
+    uint32_t tot;
+    uint32_t run = block_excl_scan_256<uint32_t>(s, ws, tot);
+#pragma unroll
+    for (uint32_t q = 0; q < 16; ++q) {
+        const uint32_t lc = tid * 16u + q;
+        const uint32_t m = msk[lc + (lc >> 8)];
+        if (c0 + lc < n_chunks) pm[c0 + lc] = (run << 16) | m;
+        run += __popc(m);
+    }
+    if (tid == 0) seg_tot[blockIdx.x] = tot;  // <= 65536; local prefixes (exclusive) stay below 2^16
+}
+
+// single workgroup: in-place exclusive scan of the segment totals
+__global__ __launch_bounds__(256) void gc_index_scan(uint64_t *seg, uint64_t n_segs) {
+    __shared__ uint64_t ws[4];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t per = (n_segs + 255u) / 256u;
+    const uint64_t b = min((uint64_t)tid * per, n_segs), e = min(b + per, n_segs);
+    uint64_t s = 0;
+    for (uint64_t i = b; i < e; ++i) s += seg[i];
+    uint64_t tot;
+    uint64_t run = block_excl_scan_256<uint64_t>(s, ws, tot);
+    for (uint64_t i = b; i < e; ++i) {
+        const uint64_t v = seg[i];
+        seg[i] = run;
+        run += v;
+    }
+}
+
+__device__ __forceinline__ uint64_t gc_before(const uint32_t *pm, const uint64_t *seg, uint64_t y) {
+    const uint32_t e = pm[y >> 4];
+    return seg[y >> 16] + (e >> 16) + __popc(e & ((1u << (y & 15u)) - 1u));
+}
+
+// ---- geometry shared by host (row offsets) and device ------------------------
+struct SwGeom {
+    int32_t m_s, m_e;  // the M window, chromosome coordinates
+    int32_t n_l, n_r;  // number of L and R windows
+};
+
+// window.rs:96-124 for a single-span parent [ps,pe] and span [is,ie]
+__host__ __device__ inline void center_resize_1(int32_t ps, int32_t pe, int32_t is, int32_t ie, int32_t resize,
+                                                int32_t &os, int32_t &oe) {
+    const int32_t psize = pe - ps + 1;
+    const int32_t half_size = (ie - is + 1) / 2;
+    const int32_t mid_left = half_size == 0 ? is : is + half_size - 1;
+    const int32_t mid_right = half_size == 0 ? is : is + half_size;
+    const int32_t half_resize = resize / 2;
+    int32_t left_idx = (mid_left - ps + 1) - half_resize + 1;
+    if (left_idx < 1) left_idx = 1;
+    int32_t right_idx = (mid_right - ps + 1) + half_resize - 1;
+    if (right_idx > psize) right_idx = psize;
+    os = ps + left_idx - 1;
+    oe = ps + right_idx - 1;
+}
+
+// window.rs:3-56: M, then L windows while sw_start >= 1, then R windows while
+// sw_end <= parent.size(), at most `max` each
+__host__ __device__ inline SwGeom sw_geometry(int32_t ps, int32_t pe, int32_t fs, int32_t fe, int32_t size,
+                                              int32_t max) {
+    SwGeom g;
+    center_resize_1(ps, pe, fs, fe, size, g.m_s, g.m_e);
+    const int64_t psize = (int64_t)pe - ps + 1;
+    const int64_t m_min_idx = (int64_t)g.m_s - ps + 1, m_max_idx = (int64_t)g.m_e - ps + 1;
+    // L: sw_end = m_min_idx - 1 - (d-1)*size, sw_start = sw_end - size + 1 >= 1, sw_end <= psize
+    int64_t nl = 0, nr = 0;
+    if (max > 0 && size > 0) {
+        const int64_t room_l = m_min_idx - 1;  // indices strictly left of M
+        nl = room_l >= 0 ? room_l / size : 0;
+        if (m_min_idx - 1 > psize) nl = 0;     // first L window already past the end (:33)
+        const int64_t room_r = psize - m_max_idx;
+        nr = room_r >= 0 ? room_r / size : 0;
+        if (m_max_idx + 1 < 1) nr = 0;         // first R window before the start (:30)
+        if (nl > max) nl = max;
+        if (nr > max) nr = max;
+    }
+    g.n_l = (int32_t)nl;
+    g.n_r = (int32_t)nr;
+    return g;
+}
+
+__device__ __forceinline__ float round4(float x) {  // utils.rs:135-138 with decimals = 4
+    const float y = 10000.0f;
+    return roundf(x * y) / y;
+}
+
+struct SwArgs {
+    const uint32_t *pm;
+    const uint64_t *seg;
+    uint64_t seq_off;   // buffer offset of ctg base 0
+    uint32_t len;
+    int32_t chr_start, chr_end;
+    const int32_t *fs, *fe;
+    const uint64_t *row_off;  // exclusive prefix of rows per feature
+    uint32_t nf;
+    int32_t size, max, resize;
+    gams_sw_row_t *rows;
+    uint64_t cap;
+};
+
+// gc_content of chromosome range [s,e] (inclusive) inside the ctg: count / len, f32
+__device__ __forceinline__ float range_gc(const SwArgs &a, int32_t s, int32_t e) {
+    // parent.index(): from = s - chr_start + 1 (1-based), bytes [from-1, to)
+    int64_t b0 = (int64_t)s - a.chr_start, b1 = (int64_t)e - a.chr_start + 1;
+    const float flen = (float)(int32_t)(b1 - b0);
+    b0 = b0 < 0 ? 0 : (b0 > a.len ? a.len : b0);  // never read outside the ctg
+    b1 = b1 < 0 ? 0 : (b1 > a.len ? a.len : b1);
+    const uint64_t c = gc_before(a.pm, a.seg, a.seq_off + (uint64_t)b1) -
+                       gc_before(a.pm, a.seg, a.seq_off + (uint64_t)b0);
+    return (float)(uint32_t)c / flen;
+}
+
+// one thread per (feature, slot); slot 0 = M, 1..max = L, max+1..2max = R
+__global__ __launch_bounds__(256) void sw_kernel(const SwArgs a) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t slots = 1u + 2u * (uint32_t)a.max;
+    const uint64_t f = gid / slots;
+    const uint32_t slot = (uint32_t)(gid % slots);
+    if (f >= a.nf) return;
+    const SwGeom g = sw_geometry(a.chr_start, a.chr_end, a.fs[f], a.fe[f], a.size, a.max);
+    int32_t type, dist, ws, we;
+    uint64_t row = a.row_off[f];
+    if (slot == 0) {
+        type = 0;
+        dist = 0;
+        ws = g.m_s;
+        we = g.m_e;
+    } else if (slot <= (uint32_t)a.max) {
+        dist = (int32_t)slot;
+        if (dist > g.n_l) return;
+        type = 1;
+        we = g.m_s - 1 - (dist - 1) * a.size;   // window.rs:24,48-49
+        ws = we - a.size + 1;
+        row += (uint64_t)dist;
+    } else {
+        dist = (int32_t)slot - a.max;
+        if (dist > g.n_r) return;
+        type = 2;
+        ws = g.m_e + 1 + (dist - 1) * a.size;   // window.rs:21,45-46
+        we = ws + a.size - 1;
+        row += (uint64_t)g.n_l + (uint64_t)dist;
+    }
+    if (row >= a.cap) return;
+    gams_sw_row_t r;
+    r.feature = (uint32_t)f;
+    r.type = type;
+    r.distance = dist;
+    r.start = ws;
+    r.end = we;
+    r.gc_content = round4(range_gc(a, ws, we));                         // utils.rs:161
+    // flank: center_resize(parent, window, resize) cut into size-bp tiles (sw.rs:175-178)
+    int32_t rs, re;
+    center_resize_1(a.chr_start, a.chr_end, ws, we, a.resize, rs, re);
+    const int32_t flen = re - rs + 1;
+    const int32_t nt = flen >= a.size ? (flen - a.size) / a.size + 1 : 0;  // sliding(range,size,size)
+    const float len = (float)nt;
+    float sum = 0.0f;
+    for (int32_t t = 0; t < nt; ++t) {
+        const int32_t ts = rs + t * a.size;
+        sum = sum + round4(range_gc(a, ts, ts + a.size - 1));           // stat.rs:3
+    }
+    const float mean = sum / len;                                       // stat.rs:5
+    float sq = 0.0f;
+    for (int32_t t = 0; t < nt; ++t) {
+        const int32_t ts = rs + t * a.size;
+        const float x = round4(range_gc(a, ts, ts + a.size - 1));
+        const float d = x - mean;
+        sq = sq + d * d;                                                // stat.rs:12
+    }
+    const float sd = sqrtf(sq / (len - 1.0f));                          // stat.rs:13
+    float cv;                                                           // utils.rs:169-175
+    if (mean == 0.0f || mean == 1.0f)
+        cv = 0.0f;
+    else if (mean <= 0.5f)
+        cv = sd / mean;
+    else
+        cv = sd / (1.0f - mean);
+    r.gc_mean = round4(mean);
+    r.gc_stddev = round4(sd);
+    r.gc_cv = round4(cv);
+    a.rows[row] = r;
+}
+
+}  // namespace
+
+// lazily built per seqset; owned by the seqset (freed in gams_seqset_destroy)
+int gams_seqset_gcindex(gams_gpu_t *h, gams_seqset_t *s) {
+    if (s->gcindex) return GAMS_OK;
+    gams_gcindex *ix = new gams_gcindex();
+    ix->n_chunks = s->bytes / 16;
+    ix->n_segs = (ix->n_chunks + 4095) / 4096;
+    hipError_t e = hipMalloc(&ix->d_pm, ix->n_chunks * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&ix->d_seg, (ix->n_segs + 1) * sizeof(uint64_t));
+    if (e != hipSuccess) {
+        (void)hipFree(ix->d_pm);
+        (void)hipFree(ix->d_seg);
+        delete ix;
+        return gams_fail(h, GAMS_ENOMEM, std::string("gcindex: hipMalloc: ") + hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(gc_index_build, dim3((unsigned)ix->n_segs), dim3(256), 0, h->compute, s->d_seq,
+                       ix->n_chunks, ix->d_pm, ix->d_seg);
+    hipLaunchKernelGGL(gc_index_scan, dim3(1), dim3(256), 0, h->compute, ix->d_seg, ix->n_segs);
+    e = hipGetLastError();
+    if (e != hipSuccess) {
+        (void)hipFree(ix->d_pm);
+        (void)hipFree(ix->d_seg);
+        delete ix;
+        return gams_fail(h, GAMS_EHIP, std::string("gcindex: launch: ") + hipGetErrorString(e));
+    }
+    s->gcindex = ix;
+    return GAMS_OK;
+}
+
+void gams_seqset_gcindex_free(gams_seqset_t *s) {
+    if (!s->gcindex) return;
+    (void)hipFree(s->gcindex->d_pm);
+    (void)hipFree(s->gcindex->d_seg);
+    delete s->gcindex;
+    s->gcindex = nullptr;
+}
+
+extern "C" int gams_gpu_sw(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, int32_t chr_start,
+                           const int32_t *feat_start, const int32_t *feat_end, uint32_t nf, int32_t size,
+                           int32_t max, int32_t resize, gams_sw_row_t *rows, uint64_t cap, uint64_t *n_rows) {
+    if (!h || !s || !n_rows || (nf && (!feat_start || !feat_end)))
+        return gams_fail(h, GAMS_EINVAL, "gpu_sw: null argument");
+    if (i >= s->n_ctg) return gams_fail(h, GAMS_EINVAL, "gpu_sw: ctg index out of range");
+    if (size <= 0 || max < 0 || resize < 0) return gams_fail(h, GAMS_EINVAL, "gpu_sw: size > 0, max >= 0, resize >= 0");
+    if (s->len[i] == 0 || s->len[i] > 0x7fffffffu) return gams_fail(h, GAMS_EINVAL, "gpu_sw: ctg length out of range");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    *n_rows = 0;
+    if (nf == 0) return GAMS_OK;
+    int rc = gams_seqset_gcindex(h, s);
+    if (rc != GAMS_OK) return rc;
+    const int32_t chr_end = chr_start + (int32_t)s->len[i] - 1;
+    // rows per feature in closed form (window.rs:29-41) -> exclusive offsets
+    std::vector<uint64_t> off(nf + 1);
+    uint64_t tot = 0;
+    for (uint32_t f = 0; f < nf; ++f) {
+        off[f] = tot;
+        const SwGeom g = sw_geometry(chr_start, chr_end, feat_start[f], feat_end[f], size, max);
+        tot += 1u + (uint64_t)g.n_l + (uint64_t)g.n_r;
+    }
+    off[nf] = tot;
+    *n_rows = tot;
+    if (!rows || cap == 0) return GAMS_OK;  // size query
+    const uint64_t n_out = std::min<uint64_t>(tot, cap);
+    int32_t *d_fs = nullptr, *d_fe = nullptr;
+    uint64_t *d_off = nullptr;
+    gams_sw_row_t *d_rows = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_fs);
+        (void)hipFree(d_fe);
+        (void)hipFree(d_off);
+        (void)hipFree(d_rows);
+    };
+#define SW_HIP(call)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            cleanup();                                                                 \
+            return gams_fail(h, GAMS_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+        }                                                                              \
+    } while (0)
+    SW_HIP(hipMalloc(&d_fs, nf * sizeof(int32_t)));
+    SW_HIP(hipMalloc(&d_fe, nf * sizeof(int32_t)));
+    SW_HIP(hipMalloc(&d_off, (nf + 1) * sizeof(uint64_t)));
+    SW_HIP(hipMalloc(&d_rows, std::max<uint64_t>(n_out, 1) * sizeof(gams_sw_row_t)));
+    SW_HIP(hipMemcpyAsync(d_fs, feat_start, nf * sizeof(int32_t), hipMemcpyHostToDevice, h->compute));
+    SW_HIP(hipMemcpyAsync(d_fe, feat_end, nf * sizeof(int32_t), hipMemcpyHostToDevice, h->compute));
+    SW_HIP(hipMemcpyAsync(d_off, off.data(), (nf + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, h->compute));
+    SwArgs a{};
+    a.pm = s->gcindex->d_pm;
+    a.seg = s->gcindex->d_seg;
+    a.seq_off = s->off[i];
+    a.len = s->len[i];
+    a.chr_start = chr_start;
+    a.chr_end = chr_end;
+    a.fs = d_fs;
+    a.fe = d_fe;
+    a.row_off = d_off;
+    a.nf = nf;
+    a.size = size;
+    a.max = max;
+    a.resize = resize;
+    a.rows = d_rows;
+    a.cap = n_out;
+    const uint64_t threads = (uint64_t)nf * (1u + 2u * (uint64_t)max);
+    const uint64_t blocks = (threads + 255) / 256;
+    if (blocks > 0x7fffffffull) {
+        cleanup();
+        return gams_fail(h, GAMS_EUNSUPPORTED, "gpu_sw: too many feature slots for one launch");
+    }
+    hipLaunchKernelGGL(sw_kernel, dim3((unsigned)blocks), dim3(256), 0, h->compute, a);
+    SW_HIP(hipGetLastError());
+    SW_HIP(hipMemcpyAsync(rows, d_rows, n_out * sizeof(gams_sw_row_t), hipMemcpyDeviceToHost, h->compute));
+    SW_HIP(hipStreamSynchronize(h->compute));
+#undef SW_HIP
+    cleanup();
+    return GAMS_OK;
+}

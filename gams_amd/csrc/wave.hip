@@ -1,0 +1,816 @@
+// wave.hip -- GC sliding windows + smoothed z-score on gfx950.
+//
+// Replaces the body of proc_ctg in the reference (src/cmd_gams/wave.rs:138-155):
+//   gams::sliding            src/libs/window.rs:78-94
+//   bio gc_content per window src/cmd_gams/wave.rs:144-153
+//   gams::thresholding_algo  src/libs/stat.rs:16-56
+// and the collection of signalled windows (wave.rs:170-187).
+//
+// One workgroup = one tile of consecutive windows of one ctg, plus the halo of
+// lag+1 windows in front of it whose gc values the z-score of the tile's first
+// windows needs (z-score state never crosses a ctg: wave.rs:294-297).
+//
+//   phase 1  tile bytes HBM -> registers (16 B/lane, coalesced), SWAR classify
+//            G/C/g/c -> 16-bit mask per 16-B chunk -> LDS
+//   phase 1b workgroup scan of the chunk popcounts -> PM[chunk] = prefix<<16 | mask
+//   phase 2  k[w] = P(w*step+size) - P(w*step)  (integer, bit-exact), and
+//            exclusive prefixes Q1 = sum k, Q2 = sum k^2 over the tile's windows
+//   phase 3  per window: S1, S2 over the lag windows the reference averages
+//            (stat.rs:51-52: filtered[i-1-lag .. i-1), or [0,lag) for i == lag),
+//            integer decision |n*k - S1| vs thr*sqrt(n*V/(n-1)) with a rigorous
+//            guard band; windows inside the band are re-evaluated in the
+//            reference's exact f32 order (three sequential passes), so signals
+//            are bit-identical to the reference.
+//   phase 4  ordered compaction of signal != 0 windows / dense rows.
+//
+// influence != 1 makes filtered[] (stat.rs:42) a true serial recurrence: those
+// runs use wave_serial_kernel (one lane per ctg, exact f32 order).
+//
+// Compile with -ffp-contract=off: the exact path must not fuse (x-m)*(x-m)+acc.
+
+#include "common.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <type_traits>
+
+namespace {
+
+struct WaveCtgDev {
+    uint64_t seq_off;   // byte offset of the ctg in the seqset buffer (256-B aligned)
+    uint64_t win_base;  // index of the ctg's window 0 in the dense outputs
+    uint32_t len;       // bases
+    uint32_t n_win;     // windows
+};
+
+struct WaveTile {
+    uint32_t ctg;
+    uint32_t w0;  // first window of the tile
+};
+
+struct WaveArgs {
+    const uint8_t *seq;
+    const WaveCtgDev *ctgs;
+    const WaveTile *tiles;
+    uint32_t size, step, lag, tw;
+    uint32_t max_chunks;  // LDS carve: PM holds max_chunks+1 words
+    uint32_t max_win;     // LDS carve: K holds max_win, Q1/Q2 hold max_win+1
+    uint32_t flags;
+    uint32_t no_signal;   // lag == 1: std is NaN (0/0), the reference never signals
+    float thr, thr_abs, fsize, flag_f, cvar;
+    float g0, g1, g2, g3;  // guard band  G = g0 + g1*S1 + g2*R + g3*D
+    // outputs
+    gams_peak_t *peaks;
+    uint64_t peak_cap;
+    unsigned long long *counters;  // [0] peaks appended, [1] exact-path evaluations
+    unsigned long long *tile_off;
+    uint32_t *tile_cnt;
+    uint32_t *dense_cnt;
+    int8_t *dense_sig;
+};
+
+// ---- G/C/g/c classification of 4 packed bytes -> 4-bit mask ------------------
+// 'C' 0x43, 'G' 0x47, 'c' 0x63, 'g' 0x67 are exactly the bytes with
+// (b & 0xDB) == 0x43 (0xDB drops the case bit 0x20 and the C/G bit 0x04).
+__device__ __forceinline__ uint32_t gc_nibble(uint32_t x) {
+    uint32_t y = (x & 0xDBDBDBDBu) ^ 0x43434343u;      // byte == 0  <=>  G/C/g/c
+    uint32_t t = (y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;      // bit 7 <- low 7 bits != 0 (no carry out)
+    uint32_t f = ~(t | y) & 0x80808080u;               // bit 7 <- byte == 0 (exact)
+    uint32_t g = f | (f >> 7);                         // bytes 0,1 -> bits 7,8 ; bytes 2,3 -> bits 23,24
+    g |= g >> 14;                                      // bytes 2,3 -> bits 9,10
+    return (g >> 7) & 0xFu;
+}
+
+__device__ __forceinline__ uint32_t gc_mask16(const uint4 v) {
+    return gc_nibble(v.x) | (gc_nibble(v.y) << 4) | (gc_nibble(v.z) << 8) | (gc_nibble(v.w) << 12);
+}
+
+// #GC in tile bytes [0, x): chunk prefix + popcount of the chunk's low bits
+__device__ __forceinline__ uint32_t gc_prefix_at(const uint32_t *PM, uint32_t x) {
+    uint32_t e = PM[x >> 4];
+    uint32_t low = e & ((1u << (x & 15u)) - 1u);  // mask lives in the low 16 bits
+    return (e >> 16) + __popc(low);
+}
+
+// The reference's evaluation, bit for bit (stat.rs:1-14 and :36-38): K holds the
+// gc counts of the tile's windows, tj = first averaged window, ti = this window.
+template <typename KT>
+__device__ __noinline__ int exact_signal(const KT *K, uint32_t tj, uint32_t ti, uint32_t n,
+                                         float fsize, float thr) {
+    const float len = (float)n;
+    float sum = 0.0f;
+    for (uint32_t q = 0; q < n; ++q) sum = sum + (float)K[tj + q] / fsize;   // mean: stat.rs:3
+    const float mean = sum / len;                                             // stat.rs:5
+    float sq = 0.0f;
+    for (uint32_t q = 0; q < n; ++q) {                                        // stat.rs:12
+        const float x = (float)K[tj + q] / fsize;
+        const float d = x - mean;
+        sq = sq + d * d;
+    }
+    const float sd = sqrtf(sq / (len - 1.0f));                                // stat.rs:13
+    const float x = (float)K[ti] / fsize;
+    if (fabsf(x - mean) > thr * sd) return x > mean ? 1 : -1;                 // stat.rs:36-38
+    return 0;
+}
+
+template <typename KT, bool WIDE>
+__global__ __launch_bounds__(256) void wave_tile_kernel(const WaveArgs a) {
+    using Q2T = typename std::conditional<WIDE, uint64_t, uint32_t>::type;
+    extern __shared__ __align__(16) unsigned char smem[];
+    // LDS carve: Q2 | Q1 | PM | scratch | PC | K
+    const uint32_t mwp = (a.max_win + 3u) & ~1u;  // even element count keeps every array 8-B aligned
+    Q2T *Q2 = reinterpret_cast<Q2T *>(smem);
+    uint32_t *Q1 = reinterpret_cast<uint32_t *>(Q2 + mwp);
+    uint32_t *PM = Q1 + mwp;
+    uint64_t *scr = reinterpret_cast<uint64_t *>(PM + ((a.max_chunks + 4) & ~1u));
+    uint32_t *PC = reinterpret_cast<uint32_t *>(scr + 8);  // 128 per-(iteration,wave) peak counts + base
+    KT *K = reinterpret_cast<KT *>(PC + 132);
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const WaveTile tl = a.tiles[blockIdx.x];
+    const WaveCtgDev cg = a.ctgs[tl.ctg];
+    const uint32_t lag = a.lag, step = a.step, size = a.size;
+    const uint32_t w0 = tl.w0;
+    const uint32_t w1 = min(w0 + a.tw, cg.n_win);
+    const uint32_t wh = w0 > lag ? w0 - lag - 1u : 0u;   // first window whose gc is needed
+    const uint32_t nw = w1 - wh;
+    const uint32_t b0 = wh * step;                        // ctg-relative byte of window wh
+    const uint32_t a0 = b0 & ~15u;                        // tile byte 0 (16-B aligned)
+    const uint32_t b1 = (w1 - 1u) * step + size;          // exclusive end, <= cg.len
+    const uint32_t nchunk = (b1 - a0 + 15u) >> 4;
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.seq + cg.seq_off + a0);
+
+    // ---- phase 1: load + classify ------------------------------------------
+    for (uint32_t c = tid; c < nchunk; c += 1024u) {
+        const uint32_t c1 = c + 256u, c2 = c + 512u, c3 = c + 768u;
+        uint4 v0 = src[c];
+        uint4 v1 = make_uint4(0, 0, 0, 0), v2 = v1, v3 = v1;
+        if (c1 < nchunk) v1 = src[c1];
+        if (c2 < nchunk) v2 = src[c2];
+        if (c3 < nchunk) v3 = src[c3];
+        PM[c] = gc_mask16(v0);
+        if (c1 < nchunk) PM[c1] = gc_mask16(v1);
+        if (c2 < nchunk) PM[c2] = gc_mask16(v2);
+        if (c3 < nchunk) PM[c3] = gc_mask16(v3);
+    }
+    __syncthreads();
+
+    // ---- phase 1b: exclusive prefix of chunk popcounts ----------------------
+    {
+        const uint32_t cpt = ((nchunk + 255u) >> 8) | 1u;  // odd stride: conflict-free LDS walks
+        const uint32_t cb = min(tid * cpt, nchunk), ce = min(cb + cpt, nchunk);
+        uint32_t s = 0;
+        for (uint32_t c = cb; c < ce; ++c) s += __popc(PM[c]);
+        uint32_t tot;
+        uint32_t run = block_excl_scan_256<uint32_t>(s, reinterpret_cast<uint32_t *>(scr), tot);
+        for (uint32_t c = cb; c < ce; ++c) {
+            const uint32_t m = PM[c];
+            PM[c] = (run << 16) | m;
+            run += __popc(m);
+        }
+        if (cb < ce && ce == nchunk) PM[nchunk] = run << 16;  // sentinel for x on the tile end
+    }
+    __syncthreads();
+
+    // ---- phase 2: window counts + prefixes of k and k^2 ---------------------
+    {
+        const uint32_t wpt = ((nw + 255u) >> 8) | 1u;
+        const uint32_t tb = min(tid * wpt, nw), te = min(tb + wpt, nw);
+        uint32_t s1 = 0;
+        Q2T s2 = 0;
+        uint32_t x = (wh + tb) * step - a0;
+        for (uint32_t t = tb; t < te; ++t, x += step) {
+            const uint32_t kk = gc_prefix_at(PM, x + size) - gc_prefix_at(PM, x);
+            K[t] = (KT)kk;
+            s1 += kk;
+            s2 += (Q2T)kk * kk;
+        }
+        uint32_t tot1;
+        Q2T tot2;
+        uint32_t q1 = block_excl_scan_256<uint32_t>(s1, reinterpret_cast<uint32_t *>(scr), tot1);
+        Q2T q2 = block_excl_scan_256<Q2T>(s2, reinterpret_cast<Q2T *>(scr), tot2);
+        for (uint32_t t = tb; t < te; ++t) {
+            Q1[t] = q1;
+            Q2[t] = q2;
+            const uint32_t kk = K[t];
+            q1 += kk;
+            q2 += (Q2T)kk * kk;
+        }
+        if (tb < te && te == nw) {
+            Q1[nw] = q1;
+            Q2[nw] = q2;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: z-score decision per window -------------------------------
+    const bool want_peaks = (a.flags & GAMS_WAVE_PEAKS) != 0;
+    const bool want_dense = (a.flags & GAMS_WAVE_DENSE) != 0;
+    const uint32_t R = a.tw >> 8;  // iterations per thread, <= 32
+    uint64_t sigbits = 0;          // 2 bits per iteration: 1 = crest, 3 = trough
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t i = w0 + (r << 8) + tid;
+        int sg = 0;
+        if (i < w1) {
+            const uint32_t ti = i - wh;
+            const uint32_t kk = K[ti];
+            if (i >= lag && !a.no_signal) {
+                const uint32_t tj = (i == lag ? 0u : i - 1u - lag) - wh;
+                const uint32_t S1 = Q1[tj + lag] - Q1[tj];
+                const Q2T S2 = Q2[tj + lag] - Q2[tj];
+                const int64_t di = (int64_t)lag * kk - (int64_t)S1;   // n*k - S1, sign = side of the mean
+                float Df, Vf;
+                if (WIDE) {
+                    const uint64_t D = (uint64_t)(di < 0 ? -di : di);
+                    const uint64_t V = (uint64_t)lag * (uint64_t)S2 - (uint64_t)S1 * S1;
+                    Df = (float)D;
+                    Vf = (float)V;
+                } else {
+                    const uint32_t D = (uint32_t)(di < 0 ? -di : di);
+                    const uint32_t V = lag * (uint32_t)S2 - S1 * S1;
+                    Df = (float)D;
+                    Vf = (float)V;
+                }
+                const float Rf = a.thr_abs * __builtin_amdgcn_sqrtf(a.cvar * Vf);
+                const float diff = Df - Rf;
+                const float G = a.g0 + a.g1 * (float)S1 + a.g2 * Rf + a.g3 * Df;
+                if (fabsf(diff) > G) {
+                    sg = diff > 0.0f ? (di > 0 ? 1 : -1) : 0;
+                } else {
+                    sg = exact_signal<KT>(K, tj, ti, lag, a.fsize, a.thr);
+                    atomicAdd(&a.counters[1], 1ull);
+                }
+            }
+            if (want_dense) {
+                a.dense_cnt[cg.win_base + i] = kk;
+                a.dense_sig[cg.win_base + i] = (int8_t)sg;
+            }
+        }
+        if (want_peaks) {
+            const unsigned long long bal = __ballot(sg != 0);
+            if (lane == 0) PC[(r << 2) + wv] = (uint32_t)__popcll(bal);
+            sigbits |= (uint64_t)(sg & 3) << (2u * r);
+        }
+    }
+
+    // ---- phase 4: ordered compaction of the tile's peaks ---------------------
+    if (want_peaks) {
+        __syncthreads();
+        const uint32_t ncell = R << 2;
+        const uint32_t mine = tid < ncell ? PC[tid] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_256<uint32_t>(mine, reinterpret_cast<uint32_t *>(scr), tot);
+        if (tid < ncell) PC[tid] = ex;
+        if (tid == 0) {
+            unsigned long long base = 0;
+            if (tot) base = atomicAdd(&a.counters[0], (unsigned long long)tot);
+            a.tile_off[blockIdx.x] = base;
+            a.tile_cnt[blockIdx.x] = tot;
+            scr[4] = base;
+        }
+        __syncthreads();
+        const unsigned long long base = scr[4];
+        if (tot) {
+            for (uint32_t r = 0; r < R; ++r) {
+                const uint32_t code = (uint32_t)(sigbits >> (2u * r)) & 3u;
+                const unsigned long long bal = __ballot(code != 0);
+                if (code) {
+                    const uint32_t i = w0 + (r << 8) + tid;
+                    const unsigned long long pos =
+                        base + PC[(r << 2) + wv] + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (pos < a.peak_cap) {
+                        gams_peak_t pk;
+                        pk.ctg = tl.ctg;
+                        pk.window = i;
+                        pk.gc_count = K[i - wh];
+                        pk.signal = code == 1u ? 1 : -1;
+                        a.peaks[pos] = pk;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- influence != 1: the filtered[] recurrence is serial per ctg -------------
+// One lane per ctg, the reference's loop verbatim (stat.rs:16-56) over the dense
+// gc counts a counts-only pass of wave_tile_kernel left in HBM.  `ring` holds
+// filtered[] for the ctg (n_win floats, written once, read lag times).
+__global__ void wave_serial_kernel(const WaveCtgDev *ctgs, uint32_t n_ctg, const uint32_t *dense_cnt,
+                                   int8_t *dense_sig, float *filtered, uint32_t lag, float thr,
+                                   float influence, float fsize) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_ctg) return;
+    const WaveCtgDev cg = ctgs[c];
+    const uint32_t n = cg.n_win;
+    const uint32_t *k = dense_cnt + cg.win_base;
+    int8_t *sig = dense_sig + cg.win_base;
+    float *f = filtered + cg.win_base;
+    const float len = (float)lag;
+    for (uint32_t i = 0; i < n; ++i) {
+        f[i] = (float)k[i] / fsize;   // filtered_data = data.to_owned()  (stat.rs:21)
+        sig[i] = 0;
+    }
+    if (n < lag || lag == 0) return;
+    float avg, sd;
+    {
+        float sum = 0.0f;
+        for (uint32_t q = 0; q < lag; ++q) sum = sum + f[q];
+        avg = sum / len;
+        float sq = 0.0f;
+        for (uint32_t q = 0; q < lag; ++q) {
+            const float d = f[q] - avg;
+            sq = sq + d * d;
+        }
+        sd = sqrtf(sq / (len - 1.0f));
+    }
+    for (uint32_t i = lag; i < n; ++i) {
+        const float x = (float)k[i] / fsize;
+        if (fabsf(x - avg) > thr * sd) {                               // stat.rs:36
+            sig[i] = x > avg ? 1 : -1;
+            const float a = influence * x;
+            const float b = (1.0f - influence) * f[i - 1];
+            f[i] = a + b;                                              // stat.rs:42
+        } else {
+            f[i] = x;
+        }
+        float sum = 0.0f;
+        for (uint32_t q = i - lag; q < i; ++q) sum = sum + f[q];       // stat.rs:51
+        avg = sum / len;
+        float sq = 0.0f;
+        for (uint32_t q = i - lag; q < i; ++q) {                       // stat.rs:52
+            const float d = f[q] - avg;
+            sq = sq + d * d;
+        }
+        sd = sqrtf(sq / (len - 1.0f));
+    }
+}
+
+// Ordered compaction of dense signals (serial path): same tile/offset scheme as
+// phase 4 of wave_tile_kernel.
+__global__ __launch_bounds__(256) void wave_compact_kernel(const WaveCtgDev *ctgs, const WaveTile *tiles,
+                                                            uint32_t tw, const uint32_t *dense_cnt,
+                                                            const int8_t *dense_sig, gams_peak_t *peaks,
+                                                            uint64_t peak_cap, unsigned long long *counters,
+                                                            unsigned long long *tile_off, uint32_t *tile_cnt) {
+    __shared__ uint32_t PC[132];
+    __shared__ uint64_t scr[8];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const WaveTile tl = tiles[blockIdx.x];
+    const WaveCtgDev cg = ctgs[tl.ctg];
+    const uint32_t w0 = tl.w0, w1 = min(w0 + tw, cg.n_win);
+    const uint32_t R = tw >> 8;
+    uint64_t sigbits = 0;
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t i = w0 + (r << 8) + tid;
+        int sg = 0;
+        if (i < w1) sg = dense_sig[cg.win_base + i];
+        const unsigned long long bal = __ballot(sg != 0);
+        if (lane == 0) PC[(r << 2) + wv] = (uint32_t)__popcll(bal);
+        sigbits |= (uint64_t)(sg & 3) << (2u * r);
+    }
+    __syncthreads();
+    const uint32_t ncell = R << 2;
+    const uint32_t mine = tid < ncell ? PC[tid] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan_256<uint32_t>(mine, reinterpret_cast<uint32_t *>(scr), tot);
+    if (tid < ncell) PC[tid] = ex;
+    if (tid == 0) {
+        unsigned long long base = 0;
+        if (tot) base = atomicAdd(&counters[0], (unsigned long long)tot);
+        tile_off[blockIdx.x] = base;
+        tile_cnt[blockIdx.x] = tot;
+        scr[4] = base;
+    }
+    __syncthreads();
+    const unsigned long long base = scr[4];
+    if (!tot) return;
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t code = (uint32_t)(sigbits >> (2u * r)) & 3u;
+        const unsigned long long bal = __ballot(code != 0);
+        if (code) {
+            const uint32_t i = w0 + (r << 8) + tid;
+            const unsigned long long pos = base + PC[(r << 2) + wv] + __popcll(bal & ((1ull << lane) - 1ull));
+            if (pos < peak_cap) {
+                gams_peak_t pk;
+                pk.ctg = tl.ctg;
+                pk.window = i;
+                pk.gc_count = dense_cnt[cg.win_base + i];
+                pk.signal = code == 1u ? 1 : -1;
+                peaks[pos] = pk;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// =============================================================================
+// host side
+// =============================================================================
+struct gams_wave_plan {
+    gams_seqset_t *set = nullptr;
+    gams_wave_params_t prm{};
+    uint32_t flags = 0;
+    bool serial = false;          // influence != 1
+    bool wide = false, k16 = false;
+    uint32_t tw = 0;              // windows per tile
+    uint32_t max_chunks = 0, max_win = 0;
+    size_t lds_bytes = 0;
+    uint64_t total_windows = 0;
+    std::vector<WaveCtgDev> ctgs;
+    std::vector<WaveTile> tiles;
+    // device
+    WaveCtgDev *d_ctgs = nullptr;
+    WaveTile *d_tiles = nullptr;
+    gams_peak_t *d_peaks = nullptr;
+    uint64_t peak_cap = 0;
+    unsigned long long *d_counters = nullptr;
+    unsigned long long *d_tile_off = nullptr;
+    uint32_t *d_tile_cnt = nullptr;
+    uint32_t *d_dense_cnt = nullptr;
+    int8_t *d_dense_sig = nullptr;
+    float *d_filtered = nullptr;
+    // host results
+    std::vector<gams_peak_t> h_peaks;
+    std::vector<gams_peak_t> h_sorted;
+    std::vector<unsigned long long> h_tile_off;
+    std::vector<uint32_t> h_tile_cnt;
+    bool ran = false;
+    bool attr_set = false;        // dynamic-LDS attribute applied for the current geometry
+    float g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+};
+
+namespace {
+
+constexpr uint32_t kMaxTileBytes = 65520;  // chunk prefix is 16 bits
+constexpr uint32_t kMaxTw = 8192;          // 2 bits/iteration in a 64-bit register
+
+size_t wave_lds_bytes(uint32_t max_chunks, uint32_t max_win, bool wide, bool k16) {
+    size_t b = 0;
+    const size_t mwp = (max_win + 3u) & ~1u;
+    b += mwp * (wide ? 8 : 4);                        // Q2
+    b += mwp * 4;                                     // Q1
+    b += (size_t)((max_chunks + 4) & ~1u) * 4;        // PM
+    b += 8 * 8;                                       // scratch
+    b += 132 * 4;                                     // PC
+    b += (size_t)(max_win + 8) * (k16 ? 2 : 1);       // K
+    return (b + 15) & ~(size_t)15;
+}
+
+// Guard band of the integer decision, in units of D = |n*k - S1| (see DESIGN.md
+// "z-score guard band" for the derivation).  u = 2^-24.
+void wave_guard_band(const gams_wave_params_t &p, float g[4]) {
+    const double u = std::ldexp(1.0, -24);
+    const double n = (double)p.lag, sz = (double)p.size;
+    const double thr = std::fabs((double)p.threshold);
+    if (!(std::isfinite(p.threshold)) || p.threshold < 0.0f || p.lag < 2) {
+        g[0] = INFINITY;  // every window takes the exact path
+        g[1] = g[2] = g[3] = 0.0f;
+        return;
+    }
+    const double gam = 1.01 * (n + 1.0) * u / (1.0 - (n + 1.0) * u);  // f32 sequential mean
+    const double kap = std::sqrt(n / (n - 1.0));
+    const double eta = 1.01 * ((n + 3.0) / 2.0 + 2.0) * u;              // sq sum, /, sqrt, *thr
+    const double safety = 2.0;
+    g[1] = (float)(safety * (gam + 2.0 * u + thr * kap * gam * (1.0 + eta)));
+    g[2] = (float)(safety * (eta + 8.0 * u));
+    g[3] = (float)(safety * 3.0 * u);
+    g[0] = (float)(safety * (2.0 * thr * kap * u * n * sz) + 1e-3);
+}
+
+int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
+    const gams_wave_params_t &q = p->prm;
+    const uint64_t halo_bytes = (uint64_t)(q.lag + 1) * q.step + (uint64_t)q.size + 32;
+    uint32_t tw = tw_req;
+    if (tw == 0) {
+        // default: ~40 KB of bases per tile, 3 workgroups per CU
+        uint64_t budget = 40960 > halo_bytes ? 40960 - halo_bytes : 0;
+        tw = (uint32_t)std::min<uint64_t>(budget / (uint64_t)q.step, 4096);
+    }
+    tw = std::min(tw, kMaxTw) & ~255u;
+    if (tw < 256) tw = 256;
+    while (tw > 256 && halo_bytes + (uint64_t)tw * q.step > kMaxTileBytes) tw -= 256;
+    if (halo_bytes + (uint64_t)tw * q.step > kMaxTileBytes)
+        return gams_fail(h, GAMS_EUNSUPPORTED,
+                         "wave: (lag+1)*step + size + 256*step exceeds the 64 KB tile of the fused kernel");
+    p->tw = tw;
+    p->max_win = tw + q.lag + 1;
+    p->max_chunks = (uint32_t)((halo_bytes + (uint64_t)tw * q.step + 15) / 16) + 1;
+    p->k16 = q.size > 255;
+    // narrow integer path: V = n*S2 - S1^2 and the tile prefix of k^2 fit 32 bits
+    const uint64_t ns = (uint64_t)q.lag * (uint64_t)q.size;
+    const uint64_t q2max = (uint64_t)(p->max_win + 1) * (uint64_t)q.size * (uint64_t)q.size;
+    p->wide = !(ns <= 65535 && q2max < (1ull << 32));
+    p->lds_bytes = wave_lds_bytes(p->max_chunks, p->max_win, p->wide, p->k16);
+    p->attr_set = false;
+    if (p->lds_bytes > 160 * 1024)
+        return gams_fail(h, GAMS_EUNSUPPORTED, "wave: tile does not fit the 160 KB LDS");
+    p->tiles.clear();
+    for (uint32_t c = 0; c < p->set->n_ctg; ++c) {
+        const uint32_t n = p->ctgs[c].n_win;
+        for (uint32_t w = 0; w < n; w += tw) p->tiles.push_back(WaveTile{c, w});
+    }
+    return GAMS_OK;
+}
+
+int wave_upload_geometry(gams_gpu_t *h, gams_wave_plan_t *p) {
+    if (p->d_tiles) (void)hipFree(p->d_tiles);
+    if (p->d_tile_off) (void)hipFree(p->d_tile_off);
+    if (p->d_tile_cnt) (void)hipFree(p->d_tile_cnt);
+    p->d_tiles = nullptr;
+    p->d_tile_off = nullptr;
+    p->d_tile_cnt = nullptr;
+    const size_t nt = std::max<size_t>(p->tiles.size(), 1);
+    GAMS_HIP(h, hipMalloc(&p->d_tiles, nt * sizeof(WaveTile)));
+    GAMS_HIP(h, hipMalloc(&p->d_tile_off, nt * sizeof(unsigned long long)));
+    GAMS_HIP(h, hipMalloc(&p->d_tile_cnt, nt * sizeof(uint32_t)));
+    if (!p->tiles.empty())
+        GAMS_HIP(h, hipMemcpy(p->d_tiles, p->tiles.data(), p->tiles.size() * sizeof(WaveTile),
+                              hipMemcpyHostToDevice));
+    return GAMS_OK;
+}
+
+template <typename KT, bool WIDE>
+int wave_launch(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a) {
+    auto kern = wave_tile_kernel<KT, WIDE>;
+    if (!p->attr_set) {
+        GAMS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+        p->attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)p->tiles.size()), dim3(256), p->lds_bytes, h->compute, a);
+    GAMS_HIP(h, hipGetLastError());
+    return GAMS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t gams_window_count(int64_t len, int32_t size, int32_t step) {
+    if (size <= 0 || step <= 0) return -1;
+    if (len < size) return 0;
+    return (len - size) / step + 1;  // window.rs:78-94 in closed form
+}
+
+int gams_wave_plan_create(gams_gpu_t *h, gams_seqset_t *s, const gams_wave_params_t *params, uint32_t flags,
+                          gams_wave_plan_t **out) {
+    if (!h || !s || !params || !out) return gams_fail(h, GAMS_EINVAL, "wave_plan_create: null argument");
+    if (!(flags & (GAMS_WAVE_PEAKS | GAMS_WAVE_DENSE)))
+        return gams_fail(h, GAMS_EINVAL, "wave_plan_create: flags must request PEAKS and/or DENSE");
+    if (params->size <= 0 || params->step <= 0)
+        return gams_fail(h, GAMS_EINVAL, "wave: size and step must be positive");
+    if (params->lag == 0) return gams_fail(h, GAMS_ESHORT, "wave: lag == 0 (the reference panics, stat.rs:30)");
+    if (params->size > 65535 || params->lag > 65535)
+        return gams_fail(h, GAMS_EUNSUPPORTED, "wave: size and lag are limited to 65535");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    gams_wave_plan_t *p = new gams_wave_plan_t();
+    p->set = s;
+    p->prm = *params;
+    p->flags = flags;
+    p->serial = !(params->influence == 1.0f);
+    p->ctgs.resize(s->n_ctg);
+    uint64_t base = 0;
+    for (uint32_t c = 0; c < s->n_ctg; ++c) {
+        const int64_t n = gams_window_count(s->len[c], params->size, params->step);
+        if (n < (int64_t)params->lag) {
+            delete p;
+            return gams_fail(h, GAMS_ESHORT,
+                             "wave: ctg " + std::to_string(c) + " has " + std::to_string(n) +
+                                 " windows < lag (the reference panics, stat.rs:30)");
+        }
+        p->ctgs[c] = WaveCtgDev{s->off[c], base, s->len[c], (uint32_t)n};
+        base += (uint64_t)n;
+    }
+    p->total_windows = base;
+    int rc = wave_build_geometry(h, p, 0);
+    if (rc != GAMS_OK) {
+        delete p;
+        return rc;
+    }
+    {
+        float g[4];
+        wave_guard_band(p->prm, g);
+        p->g0 = g[0];
+        p->g1 = g[1];
+        p->g2 = g[2];
+        p->g3 = g[3];
+    }
+    auto fail = [&](int code) {
+        gams_wave_plan_destroy(h, p);
+        return code;
+    };
+#define PLAN_HIP(call)                                                                    \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            h->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            return fail(GAMS_EHIP);                                                       \
+        }                                                                                 \
+    } while (0)
+    PLAN_HIP(hipMalloc(&p->d_ctgs, std::max<size_t>(s->n_ctg, 1) * sizeof(WaveCtgDev)));
+    if (s->n_ctg)
+        PLAN_HIP(hipMemcpy(p->d_ctgs, p->ctgs.data(), s->n_ctg * sizeof(WaveCtgDev), hipMemcpyHostToDevice));
+    rc = wave_upload_geometry(h, p);
+    if (rc != GAMS_OK) return fail(rc);
+    PLAN_HIP(hipMalloc(&p->d_counters, 4 * sizeof(unsigned long long)));
+    PLAN_HIP(hipMemset(p->d_counters, 0, 4 * sizeof(unsigned long long)));
+    const bool need_dense = (flags & GAMS_WAVE_DENSE) || p->serial;
+    if (need_dense) {
+        PLAN_HIP(hipMalloc(&p->d_dense_cnt, std::max<uint64_t>(base, 1) * sizeof(uint32_t)));
+        PLAN_HIP(hipMalloc(&p->d_dense_sig, std::max<uint64_t>(base, 1)));
+    }
+    if (p->serial) PLAN_HIP(hipMalloc(&p->d_filtered, std::max<uint64_t>(base, 1) * sizeof(float)));
+    if (flags & GAMS_WAVE_PEAKS) {
+        p->peak_cap = base / 16 + 65536;
+        PLAN_HIP(hipMalloc(&p->d_peaks, p->peak_cap * sizeof(gams_peak_t)));
+    }
+#undef PLAN_HIP
+    *out = p;
+    return GAMS_OK;
+}
+
+void gams_wave_plan_destroy(gams_gpu_t *h, gams_wave_plan_t *p) {
+    if (!p) return;
+    if (h) (void)hipSetDevice(h->device);
+    if (h && h->compute) (void)hipStreamSynchronize(h->compute);
+    (void)hipFree(p->d_ctgs);
+    (void)hipFree(p->d_tiles);
+    (void)hipFree(p->d_peaks);
+    (void)hipFree(p->d_counters);
+    (void)hipFree(p->d_tile_off);
+    (void)hipFree(p->d_tile_cnt);
+    (void)hipFree(p->d_dense_cnt);
+    (void)hipFree(p->d_dense_sig);
+    (void)hipFree(p->d_filtered);
+    delete p;
+}
+
+uint64_t gams_wave_total_windows(const gams_wave_plan_t *p) { return p ? p->total_windows : 0; }
+
+uint32_t gams_wave_ctg_windows(const gams_wave_plan_t *p, uint32_t i) {
+    return (p && i < p->ctgs.size()) ? p->ctgs[i].n_win : 0;
+}
+
+int gams_wave_plan_set_tile(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tile_windows) {
+    if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_plan_set_tile: null argument");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    GAMS_HIP(h, hipStreamSynchronize(h->compute));
+    int rc = wave_build_geometry(h, p, tile_windows);
+    if (rc != GAMS_OK) return rc;
+    p->ran = false;
+    return wave_upload_geometry(h, p);
+}
+
+int gams_wave_run(gams_gpu_t *h, gams_wave_plan_t *p) {
+    if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_run: null argument");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    GAMS_HIP(h, hipMemsetAsync(p->d_counters, 0, 4 * sizeof(unsigned long long), h->compute));
+    p->ran = true;
+    if (p->tiles.empty()) return GAMS_OK;
+    const gams_wave_params_t &q = p->prm;
+    WaveArgs a{};
+    a.seq = p->set->d_seq;
+    a.ctgs = p->d_ctgs;
+    a.tiles = p->d_tiles;
+    a.size = (uint32_t)q.size;
+    a.step = (uint32_t)q.step;
+    a.lag = q.lag;
+    a.tw = p->tw;
+    a.max_chunks = p->max_chunks;
+    a.max_win = p->max_win;
+    a.flags = p->serial ? GAMS_WAVE_DENSE : p->flags;
+    a.no_signal = (q.lag < 2 || p->serial) ? 1u : 0u;
+    a.thr = q.threshold;
+    a.thr_abs = std::fabs(q.threshold);
+    a.fsize = (float)q.size;
+    a.flag_f = (float)q.lag;
+    a.cvar = q.lag > 1 ? (float)((double)q.lag / ((double)q.lag - 1.0)) : 0.0f;
+    a.g0 = p->g0;
+    a.g1 = p->g1;
+    a.g2 = p->g2;
+    a.g3 = p->g3;
+    a.peaks = p->d_peaks;
+    a.peak_cap = p->peak_cap;
+    a.counters = p->d_counters;
+    a.tile_off = p->d_tile_off;
+    a.tile_cnt = p->d_tile_cnt;
+    a.dense_cnt = p->d_dense_cnt;
+    a.dense_sig = p->d_dense_sig;
+    int rc;
+    if (p->k16)
+        rc = p->wide ? wave_launch<uint16_t, true>(h, p, a) : wave_launch<uint16_t, false>(h, p, a);
+    else
+        rc = p->wide ? wave_launch<uint8_t, true>(h, p, a) : wave_launch<uint8_t, false>(h, p, a);
+    if (rc != GAMS_OK) return rc;
+    if (p->serial) {
+        const uint32_t n = p->set->n_ctg;
+        hipLaunchKernelGGL(wave_serial_kernel, dim3((n + 63) / 64), dim3(64), 0, h->compute, p->d_ctgs, n,
+                           p->d_dense_cnt, p->d_dense_sig, p->d_filtered, q.lag, q.threshold, q.influence,
+                           (float)q.size);
+        GAMS_HIP(h, hipGetLastError());
+        if (p->flags & GAMS_WAVE_PEAKS) {
+            hipLaunchKernelGGL(wave_compact_kernel, dim3((unsigned)p->tiles.size()), dim3(256), 0, h->compute,
+                               p->d_ctgs, p->d_tiles, p->tw, p->d_dense_cnt, p->d_dense_sig, p->d_peaks,
+                               p->peak_cap, p->d_counters, p->d_tile_off, p->d_tile_cnt);
+            GAMS_HIP(h, hipGetLastError());
+        }
+    }
+    return GAMS_OK;
+}
+
+int gams_wave_peaks(gams_gpu_t *h, gams_wave_plan_t *p, const gams_peak_t **peaks, uint64_t *n_peaks) {
+    if (!h || !p || !peaks || !n_peaks) return gams_fail(h, GAMS_EINVAL, "wave_peaks: null argument");
+    if (!(p->flags & GAMS_WAVE_PEAKS)) return gams_fail(h, GAMS_ESTATE, "wave_peaks: plan has no PEAKS output");
+    if (!p->ran) return gams_fail(h, GAMS_ESTATE, "wave_peaks: no run to read");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        GAMS_HIP(h, hipStreamSynchronize(h->compute));
+        unsigned long long cnt[4] = {0, 0, 0, 0};
+        GAMS_HIP(h, hipMemcpy(cnt, p->d_counters, sizeof cnt, hipMemcpyDeviceToHost));
+        const uint64_t total = cnt[0];
+        if (total > p->peak_cap) {
+            // grow and run again: records past the capacity were dropped
+            (void)hipFree(p->d_peaks);
+            p->d_peaks = nullptr;
+            p->peak_cap = total + total / 8 + 65536;
+            GAMS_HIP(h, hipMalloc(&p->d_peaks, p->peak_cap * sizeof(gams_peak_t)));
+            int rc = gams_wave_run(h, p);
+            if (rc != GAMS_OK) return rc;
+            continue;
+        }
+        const size_t nt = p->tiles.size();
+        p->h_peaks.resize(total);
+        p->h_sorted.resize(total);
+        p->h_tile_off.resize(nt);
+        p->h_tile_cnt.resize(nt);
+        if (total) GAMS_HIP(h, hipMemcpy(p->h_peaks.data(), p->d_peaks, total * sizeof(gams_peak_t),
+                                         hipMemcpyDeviceToHost));
+        if (nt) {
+            GAMS_HIP(h, hipMemcpy(p->h_tile_off.data(), p->d_tile_off, nt * sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost));
+            GAMS_HIP(h, hipMemcpy(p->h_tile_cnt.data(), p->d_tile_cnt, nt * sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost));
+        }
+        // tiles are in (ctg, window) order; each tile's records are contiguous and ordered
+        uint64_t o = 0;
+        for (size_t t = 0; t < nt; ++t) {
+            const uint32_t c = p->h_tile_cnt[t];
+            if (!c) continue;
+            std::memcpy(&p->h_sorted[o], &p->h_peaks[p->h_tile_off[t]], (size_t)c * sizeof(gams_peak_t));
+            o += c;
+        }
+        if (o != total) return gams_fail(h, GAMS_EHIP, "wave_peaks: tile counts do not add up");
+        *peaks = p->h_sorted.data();
+        *n_peaks = total;
+        return GAMS_OK;
+    }
+    return gams_fail(h, GAMS_EHIP, "wave_peaks: peak buffer overflow persisted");
+}
+
+int gams_wave_dense(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t i, uint32_t *gc_count, int8_t *signal) {
+    if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_dense: null argument");
+    if (!(p->flags & GAMS_WAVE_DENSE)) return gams_fail(h, GAMS_ESTATE, "wave_dense: plan has no DENSE output");
+    if (!p->ran) return gams_fail(h, GAMS_ESTATE, "wave_dense: no run to read");
+    if (i >= p->ctgs.size()) return gams_fail(h, GAMS_EINVAL, "wave_dense: ctg index out of range");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    GAMS_HIP(h, hipStreamSynchronize(h->compute));
+    const WaveCtgDev &c = p->ctgs[i];
+    if (c.n_win == 0) return GAMS_OK;
+    if (gc_count)
+        GAMS_HIP(h, hipMemcpy(gc_count, p->d_dense_cnt + c.win_base, (size_t)c.n_win * sizeof(uint32_t),
+                              hipMemcpyDeviceToHost));
+    if (signal)
+        GAMS_HIP(h, hipMemcpy(signal, p->d_dense_sig + c.win_base, (size_t)c.n_win, hipMemcpyDeviceToHost));
+    return GAMS_OK;
+}
+
+int gams_wave_exact_count(gams_gpu_t *h, gams_wave_plan_t *p, uint64_t *n_exact) {
+    if (!h || !p || !n_exact) return gams_fail(h, GAMS_EINVAL, "wave_exact_count: null argument");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    GAMS_HIP(h, hipStreamSynchronize(h->compute));
+    unsigned long long cnt[4];
+    GAMS_HIP(h, hipMemcpy(cnt, p->d_counters, sizeof cnt, hipMemcpyDeviceToHost));
+    *n_exact = cnt[1];
+    return GAMS_OK;
+}
+
+int gams_gpu_wave(gams_gpu_t *h, const uint8_t *seq, uint32_t len, const gams_wave_params_t *params,
+                  uint32_t *gc_count, int8_t *signal, uint32_t *n_windows) {
+    if (!h || !seq || !params) return gams_fail(h, GAMS_EINVAL, "gpu_wave: null argument");
+    gams_seqset_t *s = nullptr;
+    int rc = gams_seqset_create(h, 1, &len, &s);
+    if (rc != GAMS_OK) return rc;
+    rc = gams_seqset_upload(h, s, 0, seq);
+    gams_wave_plan_t *p = nullptr;
+    if (rc == GAMS_OK) rc = gams_wave_plan_create(h, s, params, GAMS_WAVE_DENSE, &p);
+    if (rc == GAMS_OK) rc = gams_wave_run(h, p);
+    if (rc == GAMS_OK) rc = gams_wave_dense(h, p, 0, gc_count, signal);
+    if (rc == GAMS_OK && n_windows) *n_windows = gams_wave_ctg_windows(p, 0);
+    if (p) gams_wave_plan_destroy(h, p);
+    gams_seqset_destroy(h, s);
+    return rc;
+}
+
+}  // extern "C"

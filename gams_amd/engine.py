@@ -1,0 +1,156 @@
+"""Thin Python objects over the C ABI (include/gams_gpu.h) for tests and bench.py.
+
+Plumbing only: every computation happens in libgams_gpu.so on the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import GamsError, WaveParams, PEAK_DTYPE, SW_ROW_DTYPE, WAVE_PEAKS, WAVE_DENSE
+
+
+def _u8(buf):
+    if isinstance(buf, np.ndarray):
+        return np.ascontiguousarray(buf, dtype=np.uint8)
+    return np.frombuffer(buf, dtype=np.uint8)
+
+
+class Engine:
+    """One handle = one device + its streams (gams_gpu_create)."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        rc = self.lib.gams_gpu_create(device, C.byref(h))
+        if rc != _lib.OK:
+            raise GamsError(rc, "gams_gpu_create failed (no HIP device?)")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gams_gpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != _lib.OK:
+            raise GamsError(rc, self.lib.gams_gpu_last_error(self.h).decode(errors="replace"))
+
+    def device_info(self):
+        arch = C.create_string_buffer(64)
+        cus, hbm = C.c_int32(), C.c_uint64()
+        self.check(self.lib.gams_gpu_device_info(self.h, arch, 64, C.byref(cus), C.byref(hbm)))
+        return arch.value.decode(), cus.value, hbm.value
+
+    def sync(self):
+        self.check(self.lib.gams_gpu_sync(self.h))
+
+    def timer_start(self):
+        self.check(self.lib.gams_gpu_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self.check(self.lib.gams_gpu_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    # ---- one-shot wave over a host buffer (wave.rs:143-155) ----
+    def wave(self, seq, size=100, step=10, lag=100, threshold=3.0, influence=1.0):
+        a = _u8(seq)
+        n = self.lib.gams_window_count(a.size, size, step)
+        if n < 0:
+            raise GamsError(_lib.EINVAL, "bad size/step")
+        cnt = np.zeros(max(n, 1), np.uint32)
+        sig = np.zeros(max(n, 1), np.int8)
+        prm = WaveParams(size, step, lag, threshold, influence)
+        nw = C.c_uint32()
+        self.check(self.lib.gams_gpu_wave(self.h, a.ctypes.data, a.size, C.byref(prm), cnt.ctypes.data,
+                                          sig.ctypes.data, C.byref(nw)))
+        return cnt[:nw.value], sig[:nw.value]
+
+
+class SeqSet:
+    """HBM image of a batch of ctg sequences (gams_seqset_*)."""
+
+    def __init__(self, eng, seqs):
+        self.eng = eng
+        self.lengths = np.array([len(s) for s in seqs], np.uint32)
+        p = C.c_void_p()
+        eng.check(eng.lib.gams_seqset_create(eng.h, len(seqs), self.lengths.ctypes.data, C.byref(p)))
+        self.p = p
+        for i, s in enumerate(seqs):
+            a = _u8(s)
+            eng.check(eng.lib.gams_seqset_upload(eng.h, self.p, i, a.ctypes.data))
+
+    def close(self):
+        if getattr(self, "p", None):
+            self.eng.lib.gams_seqset_destroy(self.eng.h, self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class WavePlan:
+    """Geometry + device buffers of one `wave` configuration over a SeqSet."""
+
+    def __init__(self, eng, seqset, size=100, step=10, lag=100, threshold=3.0, influence=1.0,
+                 flags=WAVE_PEAKS, tile_windows=0):
+        self.eng, self.seqset = eng, seqset
+        self.prm = WaveParams(size, step, lag, threshold, influence)
+        p = C.c_void_p()
+        eng.check(eng.lib.gams_wave_plan_create(eng.h, seqset.p, C.byref(self.prm), flags, C.byref(p)))
+        self.p = p
+        self.flags = flags
+        if tile_windows:
+            eng.check(eng.lib.gams_wave_plan_set_tile(eng.h, self.p, tile_windows))
+
+    @property
+    def total_windows(self):
+        return self.eng.lib.gams_wave_total_windows(self.p)
+
+    def ctg_windows(self, i):
+        return self.eng.lib.gams_wave_ctg_windows(self.p, i)
+
+    def run(self):
+        self.eng.check(self.eng.lib.gams_wave_run(self.eng.h, self.p))
+
+    def peaks(self):
+        ptr, n = C.c_void_p(), C.c_uint64()
+        self.eng.check(self.eng.lib.gams_wave_peaks(self.eng.h, self.p, C.byref(ptr), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, PEAK_DTYPE)
+        buf = (C.c_char * (n.value * PEAK_DTYPE.itemsize)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=PEAK_DTYPE).copy()
+
+    def dense(self, i):
+        n = self.ctg_windows(i)
+        cnt = np.zeros(max(n, 1), np.uint32)
+        sig = np.zeros(max(n, 1), np.int8)
+        self.eng.check(self.eng.lib.gams_wave_dense(self.eng.h, self.p, i, cnt.ctypes.data, sig.ctypes.data))
+        return cnt[:n], sig[:n]
+
+    def exact_count(self):
+        n = C.c_uint64()
+        self.eng.check(self.eng.lib.gams_wave_exact_count(self.eng.h, self.p, C.byref(n)))
+        return n.value
+
+    def close(self):
+        if getattr(self, "p", None):
+            self.eng.lib.gams_wave_plan_destroy(self.eng.h, self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,182 @@
+/*
+ * gams_gpu.h -- C ABI of the MI355X (gfx950) engine behind the `gams` hot path.
+ *
+ * This is the drop-in boundary: what a Rust host would bind with `extern "C"`
+ * in place of the CPU loops inside the reference's per-ctg workers.  No torch
+ * types, no C++ types: plain pointers and sizes.  All pointers are caller-owned
+ * HOST memory unless a function says "device-resident"; the library owns every
+ * byte of device memory, per handle.  A handle is not thread-safe; use one
+ * handle per host worker thread (the reference runs one ctg per worker,
+ * src/cmd_gams/wave.rs:288-299).  Every entry returns 0 on success or a
+ * GAMS_E* code; gams_gpu_last_error() gives the message (the reference
+ * panics instead: src/gams.rs:57, src/libs/stat.rs:30).
+ *
+ * Reference interfaces replaced (paths under wang-q/gams @ 2024-10-22):
+ *   gams_gpu_wave*            src/cmd_gams/wave.rs:138-155  (sliding + gc_content + thresholding_algo)
+ *                             = src/libs/window.rs:78-94, bio gc_content, src/libs/stat.rs:16-56
+ *   gams_gpu_sw               src/cmd_gams/sw.rs:141-184    (center_sw + cache_gc_content + cache_gc_stat)
+ *                             = src/libs/window.rs:3-56,96-124, src/libs/utils.rs:141-213
+ *   gams_gpu_count            src/libs/utils.rs:24-36       (count_rg -> Lapper::count)
+ *   gams_gpu_locate           src/libs/utils.rs:7-22        (find_one_idx -> Lapper::find().next())
+ *   gams_gpu_cover            src/cmd_gams/anno.rs:128-139  (IntSpan intersect cardinalities)
+ */
+#ifndef GAMS_GPU_H
+#define GAMS_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GAMS_OK 0
+#define GAMS_EINVAL 1       /* bad argument */
+#define GAMS_ENODEV 2       /* no usable HIP device */
+#define GAMS_ENOMEM 3       /* host or device allocation failed */
+#define GAMS_EHIP 4         /* a HIP call failed (message has the HIP error) */
+#define GAMS_ESHORT 5       /* a ctg has fewer windows than lag: the reference panics (stat.rs:30) */
+#define GAMS_EUNSUPPORTED 6 /* parameter combination outside what the kernels implement */
+#define GAMS_ESTATE 7       /* call order violated (e.g. results read before run) */
+
+typedef struct gams_gpu gams_gpu_t;
+typedef struct gams_seqset gams_seqset_t;
+typedef struct gams_wave_plan gams_wave_plan_t;
+typedef struct gams_index gams_index_t;
+typedef struct gams_spans gams_spans_t;
+
+/* ---- handle ------------------------------------------------------------ */
+int gams_gpu_create(int device, gams_gpu_t **h);
+void gams_gpu_destroy(gams_gpu_t *h);
+const char *gams_gpu_last_error(gams_gpu_t *h);
+/* name (e.g. "gfx950"), CU count, HBM bytes of the device behind the handle */
+int gams_gpu_device_info(gams_gpu_t *h, char *arch, size_t arch_len,
+                         int32_t *compute_units, uint64_t *hbm_bytes);
+/* block until everything queued on the handle's streams has finished */
+int gams_gpu_sync(gams_gpu_t *h);
+/* HIP-event stopwatch on the handle's compute stream (the stream every kernel
+ * of this library is launched on).  stop() synchronises and returns ms. */
+int gams_gpu_timer_start(gams_gpu_t *h);
+int gams_gpu_timer_stop(gams_gpu_t *h, float *ms);
+
+/* window.rs:78-94: number of size/step windows over `len` bases (-1: bad size/step) */
+int64_t gams_window_count(int64_t len, int32_t size, int32_t step);
+
+/* ---- ctg sequences resident in HBM ------------------------------------- */
+/* A seqset is the device image of a batch of `seq:{ctg}` values (gunzipped
+ * bases, 1 B/base, redis.rs:142-146): one contiguous HBM buffer, every ctg
+ * starting on a 256-B boundary.  lengths[i] = bases of ctg i. */
+int gams_seqset_create(gams_gpu_t *h, uint32_t n_ctg, const uint32_t *lengths,
+                       gams_seqset_t **s);
+/* copy ctg `i` (lengths[i] bytes) host -> HBM on the handle's copy stream */
+int gams_seqset_upload(gams_gpu_t *h, gams_seqset_t *s, uint32_t i,
+                       const uint8_t *seq);
+void gams_seqset_destroy(gams_gpu_t *h, gams_seqset_t *s);
+
+/* ---- wave (GC windows + smoothed z-score) ------------------------------- */
+typedef struct {
+    int32_t size;      /* --size      (wave.rs:125) */
+    int32_t step;      /* --step      (wave.rs:126) */
+    uint32_t lag;      /* --lag       (wave.rs:127) */
+    float threshold;   /* --threshold (wave.rs:128) */
+    float influence;   /* --influence (wave.rs:129) */
+} gams_wave_params_t;
+
+/* one signalled window, as wave.rs:170-187 collects them */
+typedef struct {
+    uint32_t ctg;      /* index into the seqset */
+    uint32_t window;   /* k: bases [k*step, k*step+size) of the ctg */
+    uint32_t gc_count; /* #{G,C,g,c}; gc_content = gc_count as f32 / size as f32 */
+    int32_t signal;    /* +1 crest, -1 trough */
+} gams_peak_t;
+
+#define GAMS_WAVE_PEAKS 1u /* compacted (ctg, window, gc_count, signal) of signal != 0 */
+#define GAMS_WAVE_DENSE 2u /* every window: gc_count u32 + signal i8 (--signal, wave.rs:158-168) */
+
+/* Geometry + device buffers for running `params` over every ctg of `s`.
+ * GAMS_ESHORT if any ctg has fewer than `lag` windows (the reference panics). */
+int gams_wave_plan_create(gams_gpu_t *h, gams_seqset_t *s,
+                          const gams_wave_params_t *params, uint32_t flags,
+                          gams_wave_plan_t **p);
+void gams_wave_plan_destroy(gams_gpu_t *h, gams_wave_plan_t *p);
+/* total windows over all ctgs, and windows of ctg i */
+uint64_t gams_wave_total_windows(const gams_wave_plan_t *p);
+uint32_t gams_wave_ctg_windows(const gams_wave_plan_t *p, uint32_t i);
+/* One pass: queue the kernels on the compute stream (asynchronous). */
+int gams_wave_run(gams_gpu_t *h, gams_wave_plan_t *p);
+/* Wait for the last run and fetch its compacted peaks, ordered by (ctg, window).
+ * *peaks points into plan-owned host memory, valid until the next run. */
+int gams_wave_peaks(gams_gpu_t *h, gams_wave_plan_t *p,
+                    const gams_peak_t **peaks, uint64_t *n_peaks);
+/* Wait for the last run and copy ctg i's dense rows (either pointer may be NULL). */
+int gams_wave_dense(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t i,
+                    uint32_t *gc_count, int8_t *signal);
+/* Tuning/diagnostics: windows per tile (0 = library default), and how many
+ * windows of the last run took the exact-order f32 re-evaluation. */
+int gams_wave_plan_set_tile(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tile_windows);
+int gams_wave_exact_count(gams_gpu_t *h, gams_wave_plan_t *p, uint64_t *n_exact);
+
+/* Convenience, one ctg from host memory (what wave.rs:143-155 computes):
+ * gc_count / signal receive n = gams_window_count(len,size,step) items. */
+int gams_gpu_wave(gams_gpu_t *h, const uint8_t *seq, uint32_t len,
+                  const gams_wave_params_t *params, uint32_t *gc_count,
+                  int8_t *signal, uint32_t *n_windows);
+
+/* ---- sw (windows around features) --------------------------------------- */
+typedef struct {
+    uint32_t feature;  /* index into the feature arrays */
+    int32_t type;      /* 0 = M, 1 = L, 2 = R  (window.rs:13-15) */
+    int32_t distance;  /* 0 for M, 1..max */
+    int32_t start;     /* chromosome coordinates, 1-based inclusive */
+    int32_t end;
+    float gc_content;  /* round4 (utils.rs:161) */
+    float gc_mean;     /* round4 (utils.rs:186) */
+    float gc_stddev;
+    float gc_cv;
+} gams_sw_row_t;
+
+/* rows per feature = 1 + nL + nR (window.rs:29-41); writes at most `cap` rows
+ * in the reference's order (feature order, then M, L1.., R1..). ctg i of `s`
+ * spans chromosome coordinates [chr_start, chr_start+len-1]. */
+int gams_gpu_sw(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, int32_t chr_start,
+                const int32_t *feat_start, const int32_t *feat_end, uint32_t nf,
+                int32_t size, int32_t max, int32_t resize, gams_sw_row_t *rows,
+                uint64_t cap, uint64_t *n_rows);
+
+/* ---- sorted-interval index (replaces rust_lapper `idx:`) ---------------- */
+/* m intervals [start, stop) (stop = end+1, redis.rs:245-248,291-294) grouped
+ * in `n_groups` groups (one per ctg for idx:rg:, one per chr for idx:ctg:);
+ * group g owns intervals [group_off[g], group_off[g+1]).  Any order inside a
+ * group: the library sorts. */
+int gams_index_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_off,
+                      const uint32_t *starts, const uint32_t *stops,
+                      gams_index_t **ix);
+void gams_index_destroy(gams_gpu_t *h, gams_index_t *ix);
+/* Lapper::count(qs,qe) per query against its group (utils.rs:35).
+ * group[q] >= n_groups (e.g. UINT32_MAX) -> 0 (utils.rs:29-32). */
+int gams_gpu_count(gams_gpu_t *h, gams_index_t *ix, const uint32_t *group,
+                   const uint32_t *qs, const uint32_t *qe, uint64_t nq,
+                   int32_t *count);
+/* Lapper::find(qs,qe).next() per query (utils.rs:16): index (into the
+ * caller's original interval order) of the first hit in (start,stop) order,
+ * or -1. */
+int gams_gpu_locate(gams_gpu_t *h, gams_index_t *ix, const uint32_t *group,
+                    const uint32_t *qs, const uint32_t *qe, uint64_t nq,
+                    int64_t *hit);
+
+/* ---- runlist coverage (anno) -------------------------------------------- */
+/* Sorted, disjoint, inclusive spans per chr group (intspan runlists). */
+int gams_spans_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_off,
+                      const int32_t *lo, const int32_t *hi, gams_spans_t **sp);
+void gams_spans_destroy(gams_gpu_t *h, gams_spans_t *sp);
+/* anno.rs:128-139: prop = |set[group] & [clip_lo,clip_hi] & [qs,qe]| as f32 /
+ * |[qs,qe]| as f32; group >= n_groups -> 0.0 */
+int gams_gpu_cover(gams_gpu_t *h, gams_spans_t *sp, const uint32_t *group,
+                   const int32_t *clip_lo, const int32_t *clip_hi,
+                   const int32_t *qs, const int32_t *qe, uint64_t nq,
+                   float *prop);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,55 @@
+"""CPU-only checks of the drop-in boundary: libgams_gpu.so loads and exports exactly the
+entry points include/gams_gpu.h declares; no compute call is made (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from gams_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "gams_gpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(gams_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_header_and_binding_agree():
+    assert declared_functions() == sorted(_lib.PROTOTYPES)
+
+
+def test_library_loads_and_exports_every_symbol():
+    lib = _lib.load()
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+
+
+def test_window_count_matches_reference_loop():
+    # window.rs:78-94
+    lib = _lib.load()
+    for length, size, step in [(230218, 100, 10), (99, 100, 10), (100, 100, 10), (109, 100, 10), (110, 100, 10),
+                               (1000, 7, 3), (5, 1, 1)]:
+        n, start = 0, 1
+        while start + size - 1 <= length:
+            n += 1
+            start += step
+        assert lib.gams_window_count(length, size, step) == n
+    assert lib.gams_window_count(100, 0, 1) == -1 and lib.gams_window_count(100, 10, 0) == -1
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.gams_gpu_create(0, C.byref(h)) == _lib.ENODEV
+    from gams_amd import engine
+
+    with pytest.raises(_lib.GamsError):
+        engine.Engine(0)

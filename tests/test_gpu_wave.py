@@ -1,0 +1,189 @@
+"""GPU parity of the wave path (through the C ABI) against the CPU oracle and the
+reference's golden peaks.  Bit-exact: gc counts, signals, compacted peaks."""
+import numpy as np
+import pytest
+
+import helpers
+from gams_amd import _lib, engine
+from oracle import oracle as ora
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = engine.Engine(0)
+    yield e
+    e.close()
+
+
+def synth(n, seed, gc=0.4, lower=0.2, nrate=1e-4):
+    rng = np.random.default_rng(seed)
+    x = np.arange(n)
+    p = gc + 0.06 * np.sin(2 * np.pi * x / 2300) + 0.04 * np.sin(2 * np.pi * x / 97000)
+    is_gc = rng.random(n) < p
+    pick = rng.random(n) < 0.5
+    s = np.where(is_gc, np.where(pick, ord("G"), ord("C")), np.where(pick, ord("A"), ord("T"))).astype(np.uint8)
+    s = np.where(rng.random(n) < lower, s | 0x20, s).astype(np.uint8)
+    s[rng.random(n) < nrate] = ord("N")
+    return s
+
+
+def check_dense(eng, seq, size, step, lag, thr, infl=1.0):
+    cnt, sig = eng.wave(seq, size, step, lag, thr, infl)
+    ocnt, _, osig = ora.wave_windows(seq, size, step, lag, thr, infl)
+    assert cnt.size == ocnt.size
+    assert np.array_equal(cnt, ocnt), f"gc_count mismatch at {np.flatnonzero(cnt != ocnt)[:5]}"
+    bad = np.flatnonzero(sig.astype(np.int32) != osig)
+    assert bad.size == 0, f"signal mismatch at {bad[:5]}: gpu {sig[bad[:5]]} oracle {osig[bad[:5]]}"
+    return cnt, sig
+
+
+def test_device_is_gfx950(eng):
+    arch, cus, hbm = eng.device_info()
+    assert arch.startswith("gfx950"), arch
+    assert cus >= 200 and hbm > 200e9
+
+
+# BASELINE config 0/1: yeast chr I, size 100 step 10 lag 100 thr 3 infl 1
+def test_chrI_dense_matches_oracle(eng, s288c):
+    cnt, sig = check_dense(eng, s288c["I"], 100, 10, 100, 3.0)
+    assert cnt.size == 23012
+    assert int((sig == 1).sum()) == 104 and int((sig == -1).sum()) == 278
+
+
+@pytest.mark.parametrize("size,step,lag,thr", [
+    (100, 1, 100, 3.0),    # config 4 geometry (step 1)
+    (100, 5, 200, 3.0),    # doc/benchmark/Atha.md:383
+    (100, 20, 50, 3.0),    # doc/benchmark/Atha.md:71
+    (50, 7, 33, 2.5),      # size not a multiple of step
+    (13, 3, 10, 2.0),
+    (255, 10, 100, 3.0),
+    (256, 10, 100, 3.0),   # gc counts need 16 bits
+    (1000, 50, 30, 2.0),
+    (100, 10, 2, 3.0),
+    (100, 10, 1, 3.0),     # lag 1: std is NaN, never signals
+    (100, 10, 600, 3.0),
+    (100, 10, 700, 3.0),   # lag*size > 65535: 64-bit variance path
+    (300, 10, 250, 3.0),   # 16-bit counts + 64-bit variance path
+    (1, 1, 20, 1.0),
+])
+def test_param_sweep_mito(eng, s288c, size, step, lag, thr):
+    check_dense(eng, s288c["Mito"], size, step, lag, thr)
+
+
+@pytest.mark.parametrize("thr", [0.0, -1.0, float("inf"), float("nan"), 0.5, 10.0])
+def test_threshold_edge_values(eng, s288c, thr):
+    check_dense(eng, s288c["Mito"][:30000], 100, 10, 100, thr)
+
+
+def test_low_complexity_and_n_runs(eng):
+    # constant stretches make std == 0 or tiny: every decision sits in the guard band
+    s = synth(200000, 7)
+    s[50000:60000] = ord("N")
+    s[90000:100000] = ord("A")
+    s[120000:130000] = ord("G")
+    s[150000:150050] = ord("N")
+    period = np.frombuffer(b"ACGTTGCAAC", np.uint8)
+    s[160000:170000] = np.tile(period, 1000)
+    check_dense(eng, s, 100, 10, 100, 3.0)
+    check_dense(eng, s, 100, 1, 100, 3.0)
+
+
+def test_non_acgt_bytes_count_in_denominator_only(eng):
+    rng = np.random.default_rng(3)
+    s = rng.integers(0, 256, 100000, dtype=np.uint8)   # arbitrary bytes, incl. 0x00 and 0xFF
+    check_dense(eng, s, 100, 10, 100, 3.0)
+
+
+def test_ragged_lengths(eng):
+    base = synth(70000, 11)
+    for n in (1090, 1091, 1099, 1100, 1101, 4095, 4096, 4097, 40959, 40960, 40961, 65521):
+        check_dense(eng, base[:n], 100, 10, 100, 3.0)
+
+
+def test_short_ctg_is_an_error_like_the_reference_panic(eng):
+    with pytest.raises(_lib.GamsError) as ei:
+        eng.wave(b"ACGT" * 100, 100, 10, 100, 3.0, 1.0)     # 31 windows < lag 100
+    assert ei.value.code == _lib.ESHORT
+    with pytest.raises(ValueError):
+        ora.wave_windows(b"ACGT" * 100, 100, 10, 100, 3.0, 1.0)
+
+
+def test_influence_below_one_serial_path(eng, s288c):
+    seq = s288c["I"][:120000]
+    for infl in (0.0, 0.5, 0.9):
+        check_dense(eng, seq, 100, 10, 100, 3.0, infl)
+
+
+def peaks_of(osig, ocnt):
+    idx = np.flatnonzero(osig != 0)
+    return idx, ocnt[idx], osig[idx]
+
+
+def test_batch_peaks_ordered_and_exact(eng, s288c):
+    # several ctgs of ragged length in one launch; peaks must come back in (ctg, window) order
+    seqs = [s288c["I"][:100000], s288c["I"][100000:], s288c["Mito"], synth(333333, 5), synth(5000, 6)]
+    ss = engine.SeqSet(eng, seqs)
+    for tile in (0, 256, 1024, 8192):
+        plan = engine.WavePlan(eng, ss, 100, 10, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS | _lib.WAVE_DENSE,
+                               tile_windows=tile)
+        plan.run()
+        pk = plan.peaks()
+        exp = []
+        for c, s in enumerate(seqs):
+            ocnt, _, osig = ora.wave_windows(s, 100, 10, 100, 3.0, 1.0)
+            cnt, sig = plan.dense(c)
+            assert np.array_equal(cnt, ocnt) and np.array_equal(sig.astype(np.int32), osig)
+            idx, k, sg = peaks_of(osig, ocnt)
+            exp += [(c, int(i), int(kk), int(g)) for i, kk, g in zip(idx, k, sg)]
+        got = [(int(r["ctg"]), int(r["window"]), int(r["gc_count"]), int(r["signal"])) for r in pk]
+        assert got == exp
+        assert plan.total_windows == sum(plan.ctg_windows(c) for c in range(len(seqs)))
+        plan.close()
+    ss.close()
+
+
+def test_golden_peaks_rows_from_gpu_peaks(eng, s288c):
+    """I.peaks.tsv rebuilt from the GPU's compacted peaks with the reference's merge rule
+    (coverage <= 1: same-sign windows whose spans intersect chain together)."""
+    seq = s288c["I"]
+    ss = engine.SeqSet(eng, [seq])
+    plan = engine.WavePlan(eng, ss, 100, 10, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS)
+    plan.run()
+    pk = plan.peaks()
+    rows = []
+    for sgn in (1, -1):
+        w = pk["window"][pk["signal"] == sgn].astype(np.int64)
+        k = pk["gc_count"][pk["signal"] == sgn]
+        i = 0
+        while i < len(w):
+            j = i
+            while j + 1 < len(w) and (w[j + 1] - w[j]) * 10 < 100:
+                j += 1
+            s, e = 1 + w[i] * 10, w[j] * 10 + 100
+            gc = ora.fmt_f32(float(np.float32(k[i]) / np.float32(100)))
+            name = f"I(+):{s}-{e}" if j > i else f"I:{s}-{e}"
+            rows.append((w[i], f"{name}\t{gc}\t{sgn}"))
+            i = j + 1
+    rows.sort()
+    out = ["#range\tgc_content\tsignal"] + [r[1] for r in rows]
+    assert out == helpers.read_lines("I.peaks.tsv")
+    plan.close()
+    ss.close()
+
+
+def test_guard_band_is_rarely_taken(eng):
+    s = synth(4_000_000, 21)
+    ss = engine.SeqSet(eng, [s])
+    plan = engine.WavePlan(eng, ss, 100, 10, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS)
+    plan.run()
+    pk = plan.peaks()
+    n_exact = plan.exact_count()
+    ocnt, _, osig = ora.wave_windows(s, 100, 10, 100, 3.0, 1.0)
+    idx = np.flatnonzero(osig)
+    assert np.array_equal(pk["window"], idx) and np.array_equal(pk["signal"], osig[idx])
+    assert np.array_equal(pk["gc_count"], ocnt[idx])
+    assert n_exact < plan.total_windows * 2e-3, n_exact
+    plan.close()
+    ss.close()
