@@ -45,8 +45,18 @@ struct WaveCtgDev {
 
 struct WaveTile {
     uint32_t ctg;
-    uint32_t w0;  // first window of the tile
+    uint32_t w0;        // first window of the tile
+    uint32_t n_win;     // windows of the ctg
+    uint32_t pad;
+    uint64_t seq_off;   // copy of the ctg's geometry: one load per workgroup instead of two dependent ones
+    uint64_t win_base;
 };
+
+// Peak records are appended through kShards independent counters (workgroup b uses shard
+// b % kShards, region shard*shard_cap of the record buffer): one contended counter word
+// serialises at ~88 atomics/us, which a 1000-tile launch would feel.
+constexpr uint32_t kShards = 128;
+constexpr uint32_t kShardWords = 16;
 
 struct WaveArgs {
     const uint8_t *seq;
@@ -61,28 +71,44 @@ struct WaveArgs {
     float g0, g1, g2, g3;  // guard band  G = g0 + g1*S1 + g2*R + g3*D
     // outputs
     gams_peak_t *peaks;
-    uint64_t peak_cap;
-    unsigned long long *counters;  // [0] peaks appended, [1] exact-path evaluations
+    uint64_t shard_cap;            // records per shard region of `peaks`
+    unsigned long long *counters;  // kShards x 16 words (one 128-B line per shard): [0] peaks appended
+                                   // to the shard's region, [1] exact-path evaluations
     unsigned long long *tile_off;
     uint32_t *tile_cnt;
     uint32_t *dense_cnt;
     int8_t *dense_sig;
+    const int8_t *const_sig;  // [size+1]: signal when the lag counts and the window's count all equal k
+    unsigned long long *stamps;  // diagnostics: [tile][8] s_memtime at phase boundaries (NULL: off)
 };
 
-// ---- G/C/g/c classification of 4 packed bytes -> 4-bit mask ------------------
+// Phase stamp of a diagnostic run (gams_wave_plan_set_stamps): thread 0 of the
+// workgroup stores the shader clock.  Off (stamps == NULL) it is one scalar branch.
+__device__ __forceinline__ void wave_stamp(const WaveArgs &a, int slot) {
+    if (a.stamps != nullptr && threadIdx.x == 0)
+        a.stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_readcyclecounter();
+}
+
+// ---- G/C/g/c classification of 16 packed bytes -> 16-bit mask ------------------
 // 'C' 0x43, 'G' 0x47, 'c' 0x63, 'g' 0x67 are exactly the bytes with
-// (b & 0xDB) == 0x43 (0xDB drops the case bit 0x20 and the C/G bit 0x04).
-__device__ __forceinline__ uint32_t gc_nibble(uint32_t x) {
-    uint32_t y = (x & 0xDBDBDBDBu) ^ 0x43434343u;      // byte == 0  <=>  G/C/g/c
-    uint32_t t = (y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;      // bit 7 <- low 7 bits != 0 (no carry out)
-    uint32_t f = ~(t | y) & 0x80808080u;               // bit 7 <- byte == 0 (exact)
-    uint32_t g = f | (f >> 7);                         // bytes 0,1 -> bits 7,8 ; bytes 2,3 -> bits 23,24
-    g |= g >> 14;                                      // bytes 2,3 -> bits 9,10
-    return (g >> 7) & 0xFu;
+// (b & 0xDB) == 0x43 (0xDB drops the case bit 0x20 and the C/G bit 0x04), i.e.
+// bit 7 clear and (b & 0x5B) == 0x43.  Per dword: t = ((x & 0x5B..) ^ 0x43..) + 0x7F..
+// sets bit 7 of every byte whose low part differs (no carry leaves a byte:
+// <= 0x5B + 0x7F), so ~(t | x) has bit 7 set exactly on G/C/g/c bytes.  On gfx950
+// this is v_bitop3 + v_add + v_bitop3.  The four flag bits of a dword are then
+// gathered by v_dot4_u32_u8 against bit weights (0x80 * weight, undone by >> 7).
+__device__ __forceinline__ uint32_t gc_flags(uint32_t x) {
+    const uint32_t t = ((x & 0x5B5B5B5Bu) ^ 0x43434343u) + 0x7F7F7F7Fu;
+    return ~(t | x | 0x7F7F7F7Fu);  // 0x80 in every G/C/g/c byte, 0 elsewhere
 }
 
 __device__ __forceinline__ uint32_t gc_mask16(const uint4 v) {
-    return gc_nibble(v.x) | (gc_nibble(v.y) << 4) | (gc_nibble(v.z) << 8) | (gc_nibble(v.w) << 12);
+    // lo = 128 * (bits 0..7 of the mask), hi = 128 * (bits 8..15)
+    uint32_t lo = __builtin_amdgcn_udot4(gc_flags(v.x), 0x08040201u, 0u, false);
+    lo = __builtin_amdgcn_udot4(gc_flags(v.y), 0x80402010u, lo, false);
+    uint32_t hi = __builtin_amdgcn_udot4(gc_flags(v.z), 0x08040201u, 0u, false);
+    hi = __builtin_amdgcn_udot4(gc_flags(v.w), 0x80402010u, hi, false);
+    return (lo >> 7) | (hi << 1);
 }
 
 // #GC in tile bytes [0, x): chunk prefix + popcount of the chunk's low bits
@@ -128,7 +154,7 @@ __global__ __launch_bounds__(256) void wave_tile_kernel(const WaveArgs a) {
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const WaveTile tl = a.tiles[blockIdx.x];
-    const WaveCtgDev cg = a.ctgs[tl.ctg];
+    const struct { uint64_t seq_off, win_base; uint32_t n_win; } cg = {tl.seq_off, tl.win_base, tl.n_win};
     const uint32_t lag = a.lag, step = a.step, size = a.size;
     const uint32_t w0 = tl.w0;
     const uint32_t w1 = min(w0 + a.tw, cg.n_win);
@@ -238,7 +264,7 @@ __global__ __launch_bounds__(256) void wave_tile_kernel(const WaveArgs a) {
                     sg = diff > 0.0f ? (di > 0 ? 1 : -1) : 0;
                 } else {
                     sg = exact_signal<KT>(K, tj, ti, lag, a.fsize, a.thr);
-                    atomicAdd(&a.counters[1], 1ull);
+                    atomicAdd(&a.counters[(blockIdx.x & (kShards - 1u)) * kShardWords + 1u], 1ull);
                 }
             }
             if (want_dense) {
@@ -261,15 +287,17 @@ __global__ __launch_bounds__(256) void wave_tile_kernel(const WaveArgs a) {
         uint32_t tot;
         const uint32_t ex = block_excl_scan_256<uint32_t>(mine, reinterpret_cast<uint32_t *>(scr), tot);
         if (tid < ncell) PC[tid] = ex;
+        const uint32_t shard = blockIdx.x & (kShards - 1u);
         if (tid == 0) {
             unsigned long long base = 0;
-            if (tot) base = atomicAdd(&a.counters[0], (unsigned long long)tot);
+            if (tot) base = atomicAdd(&a.counters[shard * kShardWords], (unsigned long long)tot);
             a.tile_off[blockIdx.x] = base;
             a.tile_cnt[blockIdx.x] = tot;
             scr[4] = base;
         }
         __syncthreads();
         const unsigned long long base = scr[4];
+        gams_peak_t *const region = a.peaks + (size_t)shard * a.shard_cap;
         if (tot) {
             for (uint32_t r = 0; r < R; ++r) {
                 const uint32_t code = (uint32_t)(sigbits >> (2u * r)) & 3u;
@@ -278,18 +306,334 @@ __global__ __launch_bounds__(256) void wave_tile_kernel(const WaveArgs a) {
                     const uint32_t i = w0 + (r << 8) + tid;
                     const unsigned long long pos =
                         base + PC[(r << 2) + wv] + __popcll(bal & ((1ull << lane) - 1ull));
-                    if (pos < a.peak_cap) {
+                    if (pos < a.shard_cap) {
                         gams_peak_t pk;
                         pk.ctg = tl.ctg;
                         pk.window = i;
                         pk.gc_count = K[i - wh];
                         pk.signal = code == 1u ? 1 : -1;
-                        a.peaks[pos] = pk;
+                        region[pos] = pk;
                     }
                 }
             }
         }
     }
+}
+
+// Same evaluation, executed by a whole wavefront for ONE window: the lanes fetch and
+// convert the lag counts in parallel; only the two f32 sums stay sequential, fed
+// lane by lane through v_readlane in the reference's order.  Every lane returns
+// the same signal.  Control flow must be wave-uniform at the call.
+__device__ __forceinline__ float readlane_f32(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+__device__ __noinline__ int exact_signal_wave(const uint8_t *K, uint32_t tj, uint32_t ti, uint32_t n,
+                                              float fsize, float thr) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const float len = (float)n;
+    float sum = 0.0f;
+    for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+        const uint32_t m = min(64u, n - c0);
+        const float x = lane < m ? (float)K[tj + c0 + lane] / fsize : 0.0f;
+        for (uint32_t l = 0; l < m; ++l) sum = sum + readlane_f32(x, (int)l);   // stat.rs:3
+    }
+    const float mean = sum / len;                                                // stat.rs:5
+    float sq = 0.0f;
+    for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+        const uint32_t m = min(64u, n - c0);
+        const float x = lane < m ? (float)K[tj + c0 + lane] / fsize : 0.0f;
+        const float d = x - mean;
+        const float dd = d * d;
+        for (uint32_t l = 0; l < m; ++l) sq = sq + readlane_f32(dd, (int)l);    // stat.rs:12
+    }
+    const float sd = sqrtf(sq / (len - 1.0f));                                   // stat.rs:13
+    const float x = (float)K[ti] / fsize;
+    if (fabsf(x - mean) > thr * sd) return x > mean ? 1 : -1;                    // stat.rs:36-38
+    return 0;
+}
+
+// const_sig[k]: the reference's verdict when the lag averaged windows and the
+// tested window all have gc count k (homopolymer / N runs: V == 0 and D == 0,
+// which the integer decision cannot settle).  One thread per k, exact order.
+__global__ void wave_const_table_kernel(int8_t *const_sig, uint32_t size, uint32_t lag, float thr) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > size) return;
+    const float fsize = (float)size, len = (float)lag;
+    const float x = (float)k / fsize;
+    float sum = 0.0f;
+    for (uint32_t q = 0; q < lag; ++q) sum = sum + x;
+    const float mean = sum / len;
+    float sq = 0.0f;
+    const float d = x - mean;
+    for (uint32_t q = 0; q < lag; ++q) sq = sq + d * d;
+    const float sd = sqrtf(sq / (len - 1.0f));
+    int sg = 0;
+    if (fabsf(x - mean) > thr * sd) sg = x > mean ? 1 : -1;
+    const_sig[k] = (int8_t)sg;
+}
+
+// =============================================================================
+// wave_fast_kernel<W>: the same tile algorithm specialised for 8-bit counts
+// (size <= 255) and 32-bit variance math (lag*size <= 65535, lag*size^2 < 2^24),
+// i.e. every BASELINE configuration.  256 threads, W windows per thread.
+//
+//   phase 1/1b as above.
+//   phase 2  interleaved over the tile's lag+1+256*W window slots: k -> K[] (u8).
+//            Slot idx holds window vb+idx with vb = w0-lag-1; windows before the
+//            ctg start (first tile only) read as k = 0.
+//   phase 3  thread t owns windows w0 + t*W + [0,W).  It sums the lag counts in
+//            front of its first window once (v_dot4 on packed bytes: S1 = sum k,
+//            S2 = sum k^2) and then rolls: S(q+1) = S(q) - K[tW+q] + K[tW+q+lag].
+//            All K traffic is whole dwords at an odd dword stride between lanes
+//            (W/4 in {1,3,5}): conflict-free.  Window i == lag averages windows
+//            [0,lag) like i == lag+1 (stat.rs:30-31 vs :51-52): it uses the
+//            rolled sums.
+//   phase 4  per-thread peak counts -> one workgroup scan -> one atomic per tile.
+// =============================================================================
+template <int W>
+__global__ __launch_bounds__(256) void wave_fast_kernel(const WaveArgs a) {
+    static_assert(W % 4 == 0 && ((W / 4) & 1) == 1, "W/4 must be odd (LDS bank stride)");
+    constexpr uint32_t TW = 256u * W;
+    constexpr int WD = W / 4;
+    extern __shared__ __align__(16) unsigned char smem[];
+    // LDS carve: PM | scratch (16 words) | K | SG (dense only)
+    uint32_t *PM = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *scr = PM + ((a.max_chunks + 4u) & ~3u);
+    uint8_t *K = reinterpret_cast<uint8_t *>(scr + 16);
+    const uint32_t *KW = reinterpret_cast<const uint32_t *>(K);
+    uint8_t *SG = K + ((TW + a.lag + 1u + 31u) & ~15u);
+
+    const uint32_t tid = threadIdx.x;
+    const WaveTile tl = a.tiles[blockIdx.x];
+    const struct { uint64_t seq_off, win_base; uint32_t n_win; } cg = {tl.seq_off, tl.win_base, tl.n_win};
+    const uint32_t lag = a.lag, step = a.step, size = a.size;
+    const uint32_t w0 = tl.w0;
+    const uint32_t w1 = min(w0 + TW, cg.n_win);
+    const uint32_t nvalid = w1 - w0;
+    const int32_t vb = (int32_t)w0 - (int32_t)lag - 1;       // window held by K slot 0 (may be < 0)
+    const uint32_t wh = vb > 0 ? (uint32_t)vb : 0u;
+    const uint32_t b0 = wh * step;
+    const uint32_t a0 = b0 & ~15u;
+    const uint32_t b1 = (w1 - 1u) * step + size;
+    const uint32_t nchunk = (b1 - a0 + 15u) >> 4;
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.seq + cg.seq_off + a0);
+
+    wave_stamp(a, 0);
+    // ---- phase 1: load + classify ------------------------------------------
+    // Two batches of four 16-B loads stay in flight per thread: the next batch is
+    // issued before the current one is classified (one exposed HBM round trip per tile).
+    {
+        uint4 cur[4], nxt[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t c = tid + 256u * k;
+            cur[k] = c < nchunk ? src[c] : make_uint4(0, 0, 0, 0);
+        }
+        for (uint32_t c0 = tid; c0 < nchunk; c0 += 1024u) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t c = c0 + 1024u + 256u * k;
+                nxt[k] = c < nchunk ? src[c] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t c = c0 + 256u * k;
+                if (c < nchunk) PM[c] = gc_mask16(cur[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
+        }
+    }
+    __syncthreads();
+    wave_stamp(a, 1);
+
+    // ---- phase 1b: exclusive prefix of chunk popcounts ----------------------
+    {
+        const uint32_t cpt = ((nchunk + 255u) >> 8) | 1u;
+        const uint32_t cb = min(tid * cpt, nchunk), ce = min(cb + cpt, nchunk);
+        uint32_t s = 0;
+        for (uint32_t c = cb; c < ce; ++c) s += __popc(PM[c]);
+        uint32_t tot;
+        uint32_t run = block_excl_scan_256<uint32_t>(s, scr, tot);
+        for (uint32_t c = cb; c < ce; ++c) {
+            const uint32_t m = PM[c];
+            PM[c] = (run << 16) | m;
+            run += __popc(m);
+        }
+        if (cb < ce && ce == nchunk) PM[nchunk] = run << 16;
+    }
+    __syncthreads();
+    wave_stamp(a, 2);
+
+    // ---- phase 2: k of every slot (interleaved: neighbouring lanes, neighbouring bytes)
+    {
+        const uint32_t nK = lag + 1u + nvalid;
+        for (uint32_t idx = tid; idx < nK; idx += 256u) {
+            const int32_t v = vb + (int32_t)idx;
+            uint32_t kk = 0;
+            if (v >= 0) {
+                const uint32_t x = (uint32_t)v * step - a0;
+                kk = gc_prefix_at(PM, x + size) - gc_prefix_at(PM, x);
+            }
+            K[idx] = (uint8_t)kk;
+        }
+    }
+    __syncthreads();
+    wave_stamp(a, 3);
+
+    // ---- phase 3: rolling sums + decision, W consecutive windows per thread ---
+    const bool want_peaks = (a.flags & GAMS_WAVE_PEAKS) != 0;
+    const bool want_dense = (a.flags & GAMS_WAVE_DENSE) != 0;
+    const uint32_t base = tid * (uint32_t)W;        // K slot of the outgoing count of window q = 0
+    uint64_t sigbits = 0;                            // 2 bits per window: 1 crest, 3 trough
+    uint32_t pend = 0;                               // windows whose decision sits inside the guard band
+    {
+        // Every thread runs this block (wave-uniform control flow): threads past the
+        // tile's last window read LDS inside the allocation and decide nothing.
+        const uint32_t bw = base >> 2;               // dword index (W % 4 == 0)
+        // outgoing counts K[base + q]
+        uint32_t og[WD];
+#pragma unroll
+        for (int d = 0; d < WD; ++d) og[d] = KW[bw + d];
+        // S1, S2 over K[base, base+lag)
+        uint32_t S1 = 0, S2 = 0;
+        const uint32_t nfull = lag >> 2;
+#pragma unroll 5
+        for (uint32_t d = 0; d < nfull; ++d) {
+            const uint32_t x = KW[bw + d];
+            S1 = __builtin_amdgcn_udot4(x, 0x01010101u, S1, false);
+            S2 = __builtin_amdgcn_udot4(x, x, S2, false);
+        }
+        const uint32_t sh = lag & 3u;                // wave-uniform
+        if (sh) {
+            const uint32_t x = KW[bw + nfull] & ((1u << (8u * sh)) - 1u);
+            S1 = __builtin_amdgcn_udot4(x, 0x01010101u, S1, false);
+            S2 = __builtin_amdgcn_udot4(x, x, S2, false);
+        }
+        // incoming/own run: bytes K[base+lag .. base+lag+W], realigned to dwords
+        uint32_t in[WD + 1];
+        {
+            const uint32_t ib = bw + nfull;
+            uint32_t lo = KW[ib];
+#pragma unroll
+            for (int d = 0; d <= WD; ++d) {
+                const uint32_t hi = KW[ib + d + 1];
+                in[d] = __builtin_amdgcn_alignbyte(hi, lo, sh);
+                lo = hi;
+            }
+        }
+        const float thr_abs = a.thr_abs, cvar = a.cvar;
+        const float g0 = a.g0, g1 = a.g1, g23 = a.g2 + a.g3;
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            const uint32_t kout = (og[q >> 2] >> (8 * (q & 3))) & 0xFFu;
+            const uint32_t kin = (in[q >> 2] >> (8 * (q & 3))) & 0xFFu;
+            const uint32_t kk = (in[(q + 1) >> 2] >> (8 * ((q + 1) & 3))) & 0xFFu;
+            const uint32_t S1n = S1 + kin - kout;
+            const uint32_t S2n = S2 + __umul24(kin, kin) - __umul24(kout, kout);
+            const uint32_t i = w0 + base + q;
+            int sg = 0;
+            if (base + q < nvalid && i >= lag && !a.no_signal) {
+                const bool first = i == lag;         // averages windows [0,lag), like i == lag+1
+                const uint32_t s1 = first ? S1n : S1;
+                const uint32_t s2 = first ? S2n : S2;
+                const int32_t di = (int32_t)__umul24(lag, kk) - (int32_t)s1;
+                const uint32_t V = __umul24(lag, s2) - __umul24(s1, s1);
+                const float Df = fabsf((float)di);
+                const float Rf = thr_abs * __builtin_amdgcn_sqrtf(cvar * (float)V);
+                const float diff = Df - Rf;
+                const float G = __builtin_fmaf(g1, (float)s1, __builtin_fmaf(g23, Df + Rf, g0));
+                if (fabsf(diff) > G) {
+                    sg = diff > 0.0f ? (di > 0 ? 1 : -1) : 0;
+                } else if ((V | (uint32_t)di) == 0u) {
+                    sg = a.const_sig[kk];            // all lag counts and this one equal kk
+                } else {
+                    pend |= 1u << q;
+                }
+            }
+            sigbits |= (uint64_t)(sg & 3) << (2 * q);
+            S1 = S1n;
+            S2 = S2n;
+        }
+    }
+    wave_stamp(a, 4);
+    // Guard-band windows: exact f32 order, one window at a time by the whole wave.
+    {
+        const uint32_t lane = tid & 63u;
+        unsigned long long bal = __ballot(pend != 0u);
+        uint32_t n_exact = 0;
+        while (bal) {
+            const int L = __ffsll(bal) - 1;                                   // wave-uniform
+            const uint32_t pL = (uint32_t)__builtin_amdgcn_readlane((int)pend, L);
+            const uint32_t q = (uint32_t)__ffs((int)pL) - 1u;
+            const uint32_t baseL = ((tid & ~63u) + (uint32_t)L) * (uint32_t)W;
+            const uint32_t first = (w0 + baseL + q == lag) ? 1u : 0u;
+            const int sg = exact_signal_wave(K, baseL + q + first, baseL + q + lag + 1u, lag, a.fsize, a.thr);
+            if (lane == (uint32_t)L) {
+                pend &= ~(1u << q);
+                sigbits |= (uint64_t)(sg & 3) << (2u * q);
+            }
+            ++n_exact;
+            bal = __ballot(pend != 0u);
+        }
+        if (n_exact && lane == 0)
+            atomicAdd(&a.counters[(blockIdx.x & (kShards - 1u)) * kShardWords + 1u], (unsigned long long)n_exact);
+    }
+
+    wave_stamp(a, 5);
+    // ---- phase 4a: dense rows, coalesced through LDS -------------------------
+    if (want_dense) {
+        if (base < nvalid) {
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+                const uint32_t code = (uint32_t)(sigbits >> (2 * q)) & 3u;
+                SG[base + q] = (uint8_t)(code == 3u ? 0xFFu : code);
+            }
+        }
+        __syncthreads();
+        for (uint32_t idx = tid; idx < nvalid; idx += 256u) {
+            a.dense_cnt[cg.win_base + w0 + idx] = K[idx + lag + 1u];
+            a.dense_sig[cg.win_base + w0 + idx] = (int8_t)SG[idx];
+        }
+    }
+
+    // ---- phase 4b: ordered compaction: thread order == window order ----------
+    if (want_peaks) {
+        // bit 0 of every 2-bit code is set for both crest (1) and trough (3)
+        const uint32_t mine = (uint32_t)__popcll(sigbits & 0x5555555555555555ull);
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_256<uint32_t>(mine, scr, tot);
+        const uint32_t shard = blockIdx.x & (kShards - 1u);
+        if (tid == 0) {
+            unsigned long long gb = 0;
+            if (tot) gb = atomicAdd(&a.counters[shard * kShardWords], (unsigned long long)tot);
+            a.tile_off[blockIdx.x] = gb;
+            a.tile_cnt[blockIdx.x] = tot;
+            reinterpret_cast<unsigned long long *>(scr + 8)[0] = gb;
+        }
+        __syncthreads();
+        if (mine) {
+            gams_peak_t *const region = a.peaks + (size_t)shard * a.shard_cap;
+            unsigned long long pos = reinterpret_cast<const unsigned long long *>(scr + 8)[0] + ex;
+            uint64_t bits = sigbits;
+            while (bits) {
+                const int q = (__ffsll((unsigned long long)bits) - 1) >> 1;
+                const uint32_t code = (uint32_t)(bits >> (2 * q)) & 3u;
+                bits &= ~(3ull << (2 * q));
+                if (pos < a.shard_cap) {
+                    gams_peak_t pk;
+                    pk.ctg = tl.ctg;
+                    pk.window = w0 + base + (uint32_t)q;
+                    pk.gc_count = K[base + (uint32_t)q + lag + 1u];
+                    pk.signal = code == 1u ? 1 : -1;
+                    region[pos] = pk;
+                }
+                ++pos;
+            }
+        }
+    }
+    wave_stamp(a, 6);
 }
 
 // ---- influence != 1: the filtered[] recurrence is serial per ctg -------------
@@ -351,13 +695,13 @@ __global__ void wave_serial_kernel(const WaveCtgDev *ctgs, uint32_t n_ctg, const
 __global__ __launch_bounds__(256) void wave_compact_kernel(const WaveCtgDev *ctgs, const WaveTile *tiles,
                                                             uint32_t tw, const uint32_t *dense_cnt,
                                                             const int8_t *dense_sig, gams_peak_t *peaks,
-                                                            uint64_t peak_cap, unsigned long long *counters,
+                                                            uint64_t shard_cap, unsigned long long *counters,
                                                             unsigned long long *tile_off, uint32_t *tile_cnt) {
     __shared__ uint32_t PC[132];
     __shared__ uint64_t scr[8];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const WaveTile tl = tiles[blockIdx.x];
-    const WaveCtgDev cg = ctgs[tl.ctg];
+    const struct { uint64_t win_base; uint32_t n_win; } cg = {tl.win_base, tl.n_win};
     const uint32_t w0 = tl.w0, w1 = min(w0 + tw, cg.n_win);
     const uint32_t R = tw >> 8;
     uint64_t sigbits = 0;
@@ -375,9 +719,10 @@ __global__ __launch_bounds__(256) void wave_compact_kernel(const WaveCtgDev *ctg
     uint32_t tot;
     const uint32_t ex = block_excl_scan_256<uint32_t>(mine, reinterpret_cast<uint32_t *>(scr), tot);
     if (tid < ncell) PC[tid] = ex;
+    const uint32_t shard = blockIdx.x & (kShards - 1u);
     if (tid == 0) {
         unsigned long long base = 0;
-        if (tot) base = atomicAdd(&counters[0], (unsigned long long)tot);
+        if (tot) base = atomicAdd(&counters[shard * kShardWords], (unsigned long long)tot);
         tile_off[blockIdx.x] = base;
         tile_cnt[blockIdx.x] = tot;
         scr[4] = base;
@@ -385,13 +730,14 @@ __global__ __launch_bounds__(256) void wave_compact_kernel(const WaveCtgDev *ctg
     __syncthreads();
     const unsigned long long base = scr[4];
     if (!tot) return;
+    peaks += (size_t)shard * shard_cap;
     for (uint32_t r = 0; r < R; ++r) {
         const uint32_t code = (uint32_t)(sigbits >> (2u * r)) & 3u;
         const unsigned long long bal = __ballot(code != 0);
         if (code) {
             const uint32_t i = w0 + (r << 8) + tid;
             const unsigned long long pos = base + PC[(r << 2) + wv] + __popcll(bal & ((1ull << lane) - 1ull));
-            if (pos < peak_cap) {
+            if (pos < shard_cap) {
                 gams_peak_t pk;
                 pk.ctg = tl.ctg;
                 pk.window = i;
@@ -414,6 +760,7 @@ struct gams_wave_plan {
     uint32_t flags = 0;
     bool serial = false;          // influence != 1
     bool wide = false, k16 = false;
+    int fast_w = 0;               // W of wave_fast_kernel (0: generic wave_tile_kernel)
     uint32_t tw = 0;              // windows per tile
     uint32_t max_chunks = 0, max_win = 0;
     size_t lds_bytes = 0;
@@ -423,9 +770,13 @@ struct gams_wave_plan {
     // device
     WaveCtgDev *d_ctgs = nullptr;
     WaveTile *d_tiles = nullptr;
-    gams_peak_t *d_peaks = nullptr;
-    uint64_t peak_cap = 0;
-    unsigned long long *d_counters = nullptr;
+    gams_peak_t *d_peaks = nullptr;             // kShards regions of shard_cap records
+    uint64_t shard_cap = 0;
+    unsigned long long *d_counters = nullptr;   // ring of kCounterRing slots x 4 words, zeroed once per lap
+    uint64_t run_idx = 0;
+    uint32_t last_slot = 0;
+    int8_t *d_const_sig = nullptr;              // [size+1], see wave_const_table_kernel
+    unsigned long long *d_stamps = nullptr;     // diagnostics, [tiles][8]
     unsigned long long *d_tile_off = nullptr;
     uint32_t *d_tile_cnt = nullptr;
     uint32_t *d_dense_cnt = nullptr;
@@ -443,6 +794,8 @@ struct gams_wave_plan {
 
 namespace {
 
+constexpr uint32_t kCounterRing = 128;       // one counter slot (kShards lines) per run: no per-run memset
+constexpr size_t kSlotWords = (size_t)kShards * kShardWords;
 constexpr uint32_t kMaxTileBytes = 65520;  // chunk prefix is 16 bits
 constexpr uint32_t kMaxTw = 8192;          // 2 bits/iteration in a 64-bit register
 
@@ -479,9 +832,58 @@ void wave_guard_band(const gams_wave_params_t &p, float g[4]) {
     g[0] = (float)(safety * (2.0 * thr * kap * u * n * sz) + 1e-3);
 }
 
+size_t wave_fast_lds_bytes(uint32_t max_chunks, uint32_t tw, uint32_t lag, bool dense) {
+    size_t b = (size_t)((max_chunks + 4u) & ~3u) * 4;   // PM
+    b += 16 * 4;                                         // scratch
+    b += (tw + lag + 1u + 31u) & ~15u;                   // K
+    if (dense) b += (tw + 15u) & ~15u;                   // SG
+    return (b + 15) & ~(size_t)15;
+}
+
+void wave_fill_tiles(gams_wave_plan_t *p) {
+    p->tiles.clear();
+    for (uint32_t c = 0; c < p->set->n_ctg; ++c) {
+        const uint32_t n = p->ctgs[c].n_win;
+        for (uint32_t w = 0; w < n; w += p->tw)
+            p->tiles.push_back(WaveTile{c, w, n, 0u, p->ctgs[c].seq_off, p->ctgs[c].win_base});
+    }
+}
+
 int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
     const gams_wave_params_t &q = p->prm;
     const uint64_t halo_bytes = (uint64_t)(q.lag + 1) * q.step + (uint64_t)q.size + 32;
+    p->fast_w = 0;
+    p->attr_set = false;
+    // fast kernel: 8-bit counts, 32-bit variance math with 24-bit multiplies
+    const bool fast_ok = !p->serial && q.size <= 255 && (uint64_t)q.lag * q.size <= 65535 &&
+                         (uint64_t)q.lag * q.size * q.size < (1ull << 24) && q.lag >= 2;
+    if (fast_ok && (tw_req == 0 || tw_req == 1024 || tw_req == 3072 || tw_req == 5120)) {
+        static const int cand[3] = {20, 12, 4};
+        int pick = 0;
+        for (int w : cand) {
+            const uint64_t tw = 256ull * w;
+            if (halo_bytes + tw * q.step > kMaxTileBytes) continue;
+            if (tw_req) {
+                if (tw_req == tw) pick = w;
+                continue;
+            }
+            // enough tiles to fill 256 CUs several times over, else smaller tiles
+            const uint64_t tiles = p->total_windows / tw;
+            if (pick == 0 && (tiles >= 2048 || w == 4)) pick = w;
+            if (pick == 0 && w == 12 && tiles >= 1024) pick = w;
+        }
+        if (pick) {
+            p->fast_w = pick;
+            p->tw = 256u * pick;
+            p->max_win = p->tw + q.lag + 1;
+            p->max_chunks = (uint32_t)((halo_bytes + (uint64_t)p->tw * q.step + 15) / 16) + 1;
+            p->k16 = false;
+            p->wide = false;
+            p->lds_bytes = wave_fast_lds_bytes(p->max_chunks, p->tw, q.lag, (p->flags & GAMS_WAVE_DENSE) != 0);
+            wave_fill_tiles(p);
+            return GAMS_OK;
+        }
+    }
     uint32_t tw = tw_req;
     if (tw == 0) {
         // default: ~40 KB of bases per tile, 3 workgroups per CU
@@ -506,11 +908,7 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
     p->attr_set = false;
     if (p->lds_bytes > 160 * 1024)
         return gams_fail(h, GAMS_EUNSUPPORTED, "wave: tile does not fit the 160 KB LDS");
-    p->tiles.clear();
-    for (uint32_t c = 0; c < p->set->n_ctg; ++c) {
-        const uint32_t n = p->ctgs[c].n_win;
-        for (uint32_t w = 0; w < n; w += tw) p->tiles.push_back(WaveTile{c, w});
-    }
+    wave_fill_tiles(p);
     return GAMS_OK;
 }
 
@@ -534,6 +932,19 @@ int wave_upload_geometry(gams_gpu_t *h, gams_wave_plan_t *p) {
 template <typename KT, bool WIDE>
 int wave_launch(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a) {
     auto kern = wave_tile_kernel<KT, WIDE>;
+    if (!p->attr_set) {
+        GAMS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+        p->attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)p->tiles.size()), dim3(256), p->lds_bytes, h->compute, a);
+    GAMS_HIP(h, hipGetLastError());
+    return GAMS_OK;
+}
+
+template <int W>
+int wave_launch_fast(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a) {
+    auto kern = wave_fast_kernel<W>;
     if (!p->attr_set) {
         GAMS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
@@ -614,8 +1025,12 @@ int gams_wave_plan_create(gams_gpu_t *h, gams_seqset_t *s, const gams_wave_param
         PLAN_HIP(hipMemcpy(p->d_ctgs, p->ctgs.data(), s->n_ctg * sizeof(WaveCtgDev), hipMemcpyHostToDevice));
     rc = wave_upload_geometry(h, p);
     if (rc != GAMS_OK) return fail(rc);
-    PLAN_HIP(hipMalloc(&p->d_counters, 4 * sizeof(unsigned long long)));
-    PLAN_HIP(hipMemset(p->d_counters, 0, 4 * sizeof(unsigned long long)));
+    PLAN_HIP(hipMalloc(&p->d_counters, kCounterRing * kSlotWords * sizeof(unsigned long long)));
+    PLAN_HIP(hipMemset(p->d_counters, 0, kCounterRing * kSlotWords * sizeof(unsigned long long)));
+    PLAN_HIP(hipMalloc(&p->d_const_sig, (size_t)params->size + 1));
+    hipLaunchKernelGGL(wave_const_table_kernel, dim3((params->size + 256) / 256), dim3(256), 0, h->compute,
+                       p->d_const_sig, (uint32_t)params->size, params->lag, params->threshold);
+    PLAN_HIP(hipGetLastError());
     const bool need_dense = (flags & GAMS_WAVE_DENSE) || p->serial;
     if (need_dense) {
         PLAN_HIP(hipMalloc(&p->d_dense_cnt, std::max<uint64_t>(base, 1) * sizeof(uint32_t)));
@@ -623,8 +1038,8 @@ int gams_wave_plan_create(gams_gpu_t *h, gams_seqset_t *s, const gams_wave_param
     }
     if (p->serial) PLAN_HIP(hipMalloc(&p->d_filtered, std::max<uint64_t>(base, 1) * sizeof(float)));
     if (flags & GAMS_WAVE_PEAKS) {
-        p->peak_cap = base / 16 + 65536;
-        PLAN_HIP(hipMalloc(&p->d_peaks, p->peak_cap * sizeof(gams_peak_t)));
+        p->shard_cap = base / 16 / kShards + 1024;
+        PLAN_HIP(hipMalloc(&p->d_peaks, p->shard_cap * kShards * sizeof(gams_peak_t)));
     }
 #undef PLAN_HIP
     *out = p;
@@ -639,6 +1054,8 @@ void gams_wave_plan_destroy(gams_gpu_t *h, gams_wave_plan_t *p) {
     (void)hipFree(p->d_tiles);
     (void)hipFree(p->d_peaks);
     (void)hipFree(p->d_counters);
+    (void)hipFree(p->d_const_sig);
+    (void)hipFree(p->d_stamps);
     (void)hipFree(p->d_tile_off);
     (void)hipFree(p->d_tile_cnt);
     (void)hipFree(p->d_dense_cnt);
@@ -660,13 +1077,20 @@ int gams_wave_plan_set_tile(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tile_wi
     int rc = wave_build_geometry(h, p, tile_windows);
     if (rc != GAMS_OK) return rc;
     p->ran = false;
+    (void)hipFree(p->d_stamps);
+    p->d_stamps = nullptr;
     return wave_upload_geometry(h, p);
 }
 
 int gams_wave_run(gams_gpu_t *h, gams_wave_plan_t *p) {
     if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_run: null argument");
     GAMS_HIP(h, hipSetDevice(h->device));
-    GAMS_HIP(h, hipMemsetAsync(p->d_counters, 0, 4 * sizeof(unsigned long long), h->compute));
+    const uint32_t slot = (uint32_t)(p->run_idx % kCounterRing);
+    if (slot == 0 && p->run_idx > 0)
+        GAMS_HIP(h, hipMemsetAsync(p->d_counters, 0, kCounterRing * kSlotWords * sizeof(unsigned long long),
+                                   h->compute));
+    ++p->run_idx;
+    p->last_slot = slot;
     p->ran = true;
     if (p->tiles.empty()) return GAMS_OK;
     const gams_wave_params_t &q = p->prm;
@@ -692,14 +1116,22 @@ int gams_wave_run(gams_gpu_t *h, gams_wave_plan_t *p) {
     a.g2 = p->g2;
     a.g3 = p->g3;
     a.peaks = p->d_peaks;
-    a.peak_cap = p->peak_cap;
-    a.counters = p->d_counters;
+    a.shard_cap = p->shard_cap;
+    a.counters = p->d_counters + kSlotWords * slot;
+    a.const_sig = p->d_const_sig;
+    a.stamps = p->d_stamps;
     a.tile_off = p->d_tile_off;
     a.tile_cnt = p->d_tile_cnt;
     a.dense_cnt = p->d_dense_cnt;
     a.dense_sig = p->d_dense_sig;
     int rc;
-    if (p->k16)
+    if (p->fast_w == 20)
+        rc = wave_launch_fast<20>(h, p, a);
+    else if (p->fast_w == 12)
+        rc = wave_launch_fast<12>(h, p, a);
+    else if (p->fast_w == 4)
+        rc = wave_launch_fast<4>(h, p, a);
+    else if (p->k16)
         rc = p->wide ? wave_launch<uint16_t, true>(h, p, a) : wave_launch<uint16_t, false>(h, p, a);
     else
         rc = p->wide ? wave_launch<uint8_t, true>(h, p, a) : wave_launch<uint8_t, false>(h, p, a);
@@ -713,7 +1145,7 @@ int gams_wave_run(gams_gpu_t *h, gams_wave_plan_t *p) {
         if (p->flags & GAMS_WAVE_PEAKS) {
             hipLaunchKernelGGL(wave_compact_kernel, dim3((unsigned)p->tiles.size()), dim3(256), 0, h->compute,
                                p->d_ctgs, p->d_tiles, p->tw, p->d_dense_cnt, p->d_dense_sig, p->d_peaks,
-                               p->peak_cap, p->d_counters, p->d_tile_off, p->d_tile_cnt);
+                               p->shard_cap, p->d_counters + kSlotWords * slot, p->d_tile_off, p->d_tile_cnt);
             GAMS_HIP(h, hipGetLastError());
         }
     }
@@ -727,15 +1159,22 @@ int gams_wave_peaks(gams_gpu_t *h, gams_wave_plan_t *p, const gams_peak_t **peak
     GAMS_HIP(h, hipSetDevice(h->device));
     for (int attempt = 0; attempt < 2; ++attempt) {
         GAMS_HIP(h, hipStreamSynchronize(h->compute));
-        unsigned long long cnt[4] = {0, 0, 0, 0};
-        GAMS_HIP(h, hipMemcpy(cnt, p->d_counters, sizeof cnt, hipMemcpyDeviceToHost));
-        const uint64_t total = cnt[0];
-        if (total > p->peak_cap) {
-            // grow and run again: records past the capacity were dropped
+        std::vector<unsigned long long> cnt(kSlotWords);
+        GAMS_HIP(h, hipMemcpy(cnt.data(), p->d_counters + kSlotWords * p->last_slot,
+                              kSlotWords * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        uint64_t total = 0, worst = 0;
+        uint64_t host_base[kShards];
+        for (uint32_t sh = 0; sh < kShards; ++sh) {
+            host_base[sh] = total;
+            total += cnt[sh * kShardWords];
+            worst = std::max<uint64_t>(worst, cnt[sh * kShardWords]);
+        }
+        if (worst > p->shard_cap) {
+            // grow and run again: records past a shard's capacity were dropped
             (void)hipFree(p->d_peaks);
             p->d_peaks = nullptr;
-            p->peak_cap = total + total / 8 + 65536;
-            GAMS_HIP(h, hipMalloc(&p->d_peaks, p->peak_cap * sizeof(gams_peak_t)));
+            p->shard_cap = worst + worst / 8 + 1024;
+            GAMS_HIP(h, hipMalloc(&p->d_peaks, p->shard_cap * kShards * sizeof(gams_peak_t)));
             int rc = gams_wave_run(h, p);
             if (rc != GAMS_OK) return rc;
             continue;
@@ -745,20 +1184,27 @@ int gams_wave_peaks(gams_gpu_t *h, gams_wave_plan_t *p, const gams_peak_t **peak
         p->h_sorted.resize(total);
         p->h_tile_off.resize(nt);
         p->h_tile_cnt.resize(nt);
-        if (total) GAMS_HIP(h, hipMemcpy(p->h_peaks.data(), p->d_peaks, total * sizeof(gams_peak_t),
-                                         hipMemcpyDeviceToHost));
-        if (nt) {
-            GAMS_HIP(h, hipMemcpy(p->h_tile_off.data(), p->d_tile_off, nt * sizeof(unsigned long long),
-                                  hipMemcpyDeviceToHost));
-            GAMS_HIP(h, hipMemcpy(p->h_tile_cnt.data(), p->d_tile_cnt, nt * sizeof(uint32_t),
-                                  hipMemcpyDeviceToHost));
+        for (uint32_t sh = 0; sh < kShards; ++sh) {
+            const uint64_t c = cnt[sh * kShardWords];
+            if (c)
+                GAMS_HIP(h, hipMemcpyAsync(p->h_peaks.data() + host_base[sh], p->d_peaks + (size_t)sh * p->shard_cap,
+                                           c * sizeof(gams_peak_t), hipMemcpyDeviceToHost, h->compute));
         }
+        if (nt) {
+            GAMS_HIP(h, hipMemcpyAsync(p->h_tile_off.data(), p->d_tile_off, nt * sizeof(unsigned long long),
+                                       hipMemcpyDeviceToHost, h->compute));
+            GAMS_HIP(h, hipMemcpyAsync(p->h_tile_cnt.data(), p->d_tile_cnt, nt * sizeof(uint32_t),
+                                       hipMemcpyDeviceToHost, h->compute));
+        }
+        GAMS_HIP(h, hipStreamSynchronize(h->compute));
         // tiles are in (ctg, window) order; each tile's records are contiguous and ordered
+        // inside the region of shard (tile % kShards)
         uint64_t o = 0;
         for (size_t t = 0; t < nt; ++t) {
             const uint32_t c = p->h_tile_cnt[t];
             if (!c) continue;
-            std::memcpy(&p->h_sorted[o], &p->h_peaks[p->h_tile_off[t]], (size_t)c * sizeof(gams_peak_t));
+            std::memcpy(&p->h_sorted[o], &p->h_peaks[host_base[t % kShards] + p->h_tile_off[t]],
+                        (size_t)c * sizeof(gams_peak_t));
             o += c;
         }
         if (o != total) return gams_fail(h, GAMS_EHIP, "wave_peaks: tile counts do not add up");
@@ -786,13 +1232,60 @@ int gams_wave_dense(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t i, uint32_t *gc
     return GAMS_OK;
 }
 
+int gams_wave_plan_set_stamps(gams_gpu_t *h, gams_wave_plan_t *p, int enable) {
+    if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_plan_set_stamps: null argument");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    GAMS_HIP(h, hipStreamSynchronize(h->compute));
+    (void)hipFree(p->d_stamps);
+    p->d_stamps = nullptr;
+    if (enable) {
+        const size_t n = std::max<size_t>(p->tiles.size(), 1) * 8;
+        GAMS_HIP(h, hipMalloc(&p->d_stamps, n * sizeof(unsigned long long)));
+        GAMS_HIP(h, hipMemset(p->d_stamps, 0, n * sizeof(unsigned long long)));
+    }
+    return GAMS_OK;
+}
+
+int gams_wave_stamps(gams_gpu_t *h, gams_wave_plan_t *p, double *mean_cycles, uint64_t *span_cycles) {
+    if (!h || !p || !mean_cycles || !span_cycles) return gams_fail(h, GAMS_EINVAL, "wave_stamps: null argument");
+    if (!p->d_stamps) return gams_fail(h, GAMS_ESTATE, "wave_stamps: stamps are off");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    GAMS_HIP(h, hipStreamSynchronize(h->compute));
+    const size_t nt = p->tiles.size();
+    std::vector<unsigned long long> st(std::max<size_t>(nt, 1) * 8);
+    GAMS_HIP(h, hipMemcpy(st.data(), p->d_stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 8; ++k) mean_cycles[k] = 0.0;
+    unsigned long long lo = ~0ull, hi = 0;
+    size_t used = 0;
+    for (size_t t = 0; t < nt; ++t) {
+        bool ok = true;  // clocks of different XCDs are not comparable; drop anything odd
+        for (int k = 0; k < 6; ++k)
+            ok &= st[t * 8 + k] != 0 && st[t * 8 + k + 1] >= st[t * 8 + k] &&
+                  st[t * 8 + k + 1] - st[t * 8 + k] < (1ull << 28);
+        if (!ok) continue;
+        ++used;
+        for (int k = 0; k < 6; ++k) mean_cycles[k] += (double)(st[t * 8 + k + 1] - st[t * 8 + k]);
+        mean_cycles[6] += (double)(st[t * 8 + 6] - st[t * 8]);
+        lo = std::min(lo, st[t * 8]);
+        hi = std::max(hi, st[t * 8 + 6]);
+    }
+    if (used)
+        for (int k = 0; k < 7; ++k) mean_cycles[k] /= (double)used;
+    mean_cycles[7] = (double)used;
+    *span_cycles = used ? hi - lo : 0;
+    return GAMS_OK;
+}
+
 int gams_wave_exact_count(gams_gpu_t *h, gams_wave_plan_t *p, uint64_t *n_exact) {
     if (!h || !p || !n_exact) return gams_fail(h, GAMS_EINVAL, "wave_exact_count: null argument");
     GAMS_HIP(h, hipSetDevice(h->device));
     GAMS_HIP(h, hipStreamSynchronize(h->compute));
-    unsigned long long cnt[4];
-    GAMS_HIP(h, hipMemcpy(cnt, p->d_counters, sizeof cnt, hipMemcpyDeviceToHost));
-    *n_exact = cnt[1];
+    std::vector<unsigned long long> cnt(kSlotWords);
+    GAMS_HIP(h, hipMemcpy(cnt.data(), p->d_counters + kSlotWords * p->last_slot,
+                          kSlotWords * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    uint64_t tot = 0;
+    for (uint32_t sh = 0; sh < kShards; ++sh) tot += cnt[sh * kShardWords + 1];
+    *n_exact = tot;
     return GAMS_OK;
 }
 

@@ -139,6 +139,16 @@ class WavePlan:
         self.eng.check(self.eng.lib.gams_wave_dense(self.eng.h, self.p, i, cnt.ctypes.data, sig.ctypes.data))
         return cnt[:n], sig[:n]
 
+    def stamps(self):
+        """Run once with phase stamps on; returns (mean cycles per phase[7], span cycles)."""
+        self.eng.check(self.eng.lib.gams_wave_plan_set_stamps(self.eng.h, self.p, 1))
+        self.run()
+        m = (C.c_double * 8)()
+        span = C.c_uint64()
+        self.eng.check(self.eng.lib.gams_wave_stamps(self.eng.h, self.p, m, C.byref(span)))
+        self.eng.check(self.eng.lib.gams_wave_plan_set_stamps(self.eng.h, self.p, 0))
+        return list(m)[:7], span.value
+
     def exact_count(self):
         n = C.c_uint64()
         self.eng.check(self.eng.lib.gams_wave_exact_count(self.eng.h, self.p, C.byref(n)))

@@ -1,0 +1,552 @@
+// gams_host.cpp -- see gams_host.hpp.  Citations are file:line under the reference.
+#include "gams_host.hpp"
+
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+namespace gams {
+
+namespace {
+
+void check(gams_gpu_t *h, int rc) {
+    if (rc != GAMS_OK) throw Error(rc, gams_gpu_last_error(h));
+}
+
+bool is_word(char c) {
+    return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_';
+}
+
+struct SeqSetGuard {
+    gams_gpu_t *h;
+    gams_seqset_t *s = nullptr;
+    ~SeqSetGuard() {
+        if (s) gams_seqset_destroy(h, s);
+    }
+};
+struct PlanGuard {
+    gams_gpu_t *h;
+    gams_wave_plan_t *p = nullptr;
+    ~PlanGuard() {
+        if (p) gams_wave_plan_destroy(h, p);
+    }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// formatting
+// ---------------------------------------------------------------------------
+std::string fmt_f32(float v) {
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v < 0 ? "-inf" : "inf";
+    char buf[128];
+    auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::fixed);  // shortest round trip
+    return std::string(buf, r.ptr);
+}
+
+std::string runlist(int64_t s, int64_t e) {
+    std::string o = std::to_string(s);
+    if (e != s) {
+        o += '-';
+        o += std::to_string(e);
+    }
+    return o;
+}
+
+// intspan::Range::from_str: [name.]chr[(strand)]:start[-end]
+Range Range::from_str(const std::string &in) {
+    Range r;
+    std::string s = in;
+    while (!s.empty() && (s.back() == '\r' || s.back() == '\n' || s.back() == ' ')) s.pop_back();
+    size_t colon = s.rfind(':');
+    if (colon == std::string::npos || colon == 0 || colon + 1 >= s.size()) return r;
+    std::string head = s.substr(0, colon), tail = s.substr(colon + 1);
+    // start[-_]end
+    size_t i = 0;
+    while (i < tail.size() && tail[i] >= '0' && tail[i] <= '9') ++i;
+    if (i == 0 || i > 10) return r;
+    long long st = std::atoll(tail.substr(0, i).c_str()), en = st;
+    if (i < tail.size()) {
+        size_t j = i;
+        while (j < tail.size() && (tail[j] == '-' || tail[j] == '_')) ++j;
+        if (j == i) return r;
+        size_t k = j;
+        while (k < tail.size() && tail[k] >= '0' && tail[k] <= '9') ++k;
+        if (k == j || k != tail.size() || k - j > 10) return r;
+        en = std::atoll(tail.substr(j, k - j).c_str());
+    }
+    if (st > INT32_MAX || en > INT32_MAX) return r;
+    // head: [name.]chr[(strand)]
+    if (!head.empty() && head.back() == ')') {
+        size_t open = head.rfind('(');
+        if (open == std::string::npos) return r;
+        r.strand = head.substr(open + 1, head.size() - open - 2);
+        head = head.substr(0, open);
+    }
+    size_t dot = head.find('.');
+    if (dot != std::string::npos) {
+        r.name = head.substr(0, dot);
+        head = head.substr(dot + 1);
+    }
+    if (head.empty()) return r;
+    for (char c : head)
+        if (!(is_word(c) || c == '-' || c == '/')) return r;
+    r.chr = head;
+    r.start = (int32_t)st;
+    r.end = (int32_t)en;
+    r.valid = true;
+    return r;
+}
+
+std::string Range::to_string() const {
+    std::string o;
+    if (!name.empty()) o += name + ".";
+    o += chr;
+    if (!strand.empty()) o += "(" + strand + ")";
+    o += ":" + runlist(start, end);
+    return o;
+}
+
+// ---------------------------------------------------------------------------
+// wave
+// ---------------------------------------------------------------------------
+namespace {
+
+// merge_ints (wave.rs:217-252) for the peaks of one sign.  All windows have the
+// same size and start at chr_start + k*step, so the intersection of windows k_i
+// < k_j has size - (k_j-k_i)*step bases and the edge test (:229-231) depends on
+// d = k_j - k_i alone: d in [dmin, dmax].  Components by union-find.
+struct Merge {
+    std::vector<int64_t> cmin, cmax;
+    std::vector<char> in_graph;
+};
+
+Merge merge_ints(const std::vector<uint32_t> &w, int32_t chr_start, int32_t size, int32_t step, float coverage) {
+    const size_t p = w.size();
+    Merge m;
+    m.cmin.resize(p);
+    m.cmax.resize(p);
+    m.in_graph.assign(p, 0);
+    std::vector<size_t> par(p);
+    std::iota(par.begin(), par.end(), (size_t)0);
+    auto find = [&](size_t x) {
+        while (par[x] != x) {
+            par[x] = par[par[x]];
+            x = par[x];
+        }
+        return x;
+    };
+    // d range with a non-empty intersection that passes both coverage tests
+    const int64_t dmax = ((int64_t)size + step - 1) / step - 1;  // largest d with d*step < size
+    int64_t dmin = dmax + 1;
+    for (int64_t d = 1; d <= dmax; ++d) {
+        const float inter = (float)(int32_t)(size - d * step);
+        const float cov = (float)size / inter;                   // cov_i == cov_j (:229-230)
+        if (cov >= coverage) {                                   // monotone in d
+            dmin = d;
+            break;
+        }
+    }
+    for (size_t i = 0; i < p; ++i) {
+        for (size_t j = i + 1; j < p; ++j) {
+            const int64_t d = (int64_t)w[j] - (int64_t)w[i];
+            if (d > dmax) break;
+            if (d >= dmin) {
+                size_t a = find(i), b = find(j);
+                if (a != b) par[b] = a;
+                m.in_graph[i] = m.in_graph[j] = 1;
+            }
+        }
+    }
+    std::vector<int64_t> mn(p, INT64_MAX), mx(p, INT64_MIN);
+    for (size_t i = 0; i < p; ++i) {
+        const size_t r = find(i);
+        const int64_t s = (int64_t)chr_start + (int64_t)w[i] * step, e = s + size - 1;
+        mn[r] = std::min(mn[r], s);
+        mx[r] = std::max(mx[r], e);
+    }
+    for (size_t i = 0; i < p; ++i) {
+        const size_t r = find(i);
+        m.cmin[i] = mn[r];
+        m.cmax[i] = mx[r];
+    }
+    return m;
+}
+
+}  // namespace
+
+std::vector<std::string> wave_proc_ctgs(gams_gpu_t *h, const std::vector<Ctg> &ctgs,
+                                        const std::vector<const uint8_t *> &seqs, const WaveArgs &a) {
+    if (ctgs.size() != seqs.size()) throw Error(GAMS_EINVAL, "wave_proc_ctgs: ctgs/seqs size mismatch");
+    const uint32_t n = (uint32_t)ctgs.size();
+    std::vector<std::string> out(n);
+    if (n == 0) return out;
+    std::vector<uint32_t> lens(n);
+    for (uint32_t c = 0; c < n; ++c) lens[c] = (uint32_t)(ctgs[c].chr_end - ctgs[c].chr_start + 1);
+    SeqSetGuard sg{h};
+    check(h, gams_seqset_create(h, n, lens.data(), &sg.s));
+    for (uint32_t c = 0; c < n; ++c) check(h, gams_seqset_upload(h, sg.s, c, seqs[c]));
+    gams_wave_params_t prm{a.size, a.step, a.lag, a.threshold, a.influence};
+    PlanGuard pg{h};
+    check(h, gams_wave_plan_create(h, sg.s, &prm, a.signal ? GAMS_WAVE_DENSE : GAMS_WAVE_PEAKS, &pg.p));
+    check(h, gams_wave_run(h, pg.p));
+    const float fsize = (float)a.size;
+    if (a.signal) {                                                     // wave.rs:158-168
+        for (uint32_t c = 0; c < n; ++c) {
+            const uint32_t nw = gams_wave_ctg_windows(pg.p, c);
+            std::vector<uint32_t> cnt(nw ? nw : 1);
+            std::vector<int8_t> sig(nw ? nw : 1);
+            check(h, gams_wave_dense(h, pg.p, c, cnt.data(), sig.data()));
+            std::string &o = out[c];
+            o.reserve((size_t)nw * 24);
+            for (uint32_t i = 0; i < nw; ++i) {
+                const int64_t s = (int64_t)ctgs[c].chr_start + (int64_t)i * a.step;
+                o += ctgs[c].chr_id;
+                o += ':';
+                o += runlist(s, s + a.size - 1);
+                o += '\t';
+                o += fmt_f32((float)cnt[i] / fsize);                    // gc_content: count as f32 / len as f32
+                o += '\t';
+                o += std::to_string((int)sig[i]);
+                o += '\n';
+            }
+        }
+        return out;
+    }
+    const gams_peak_t *pk = nullptr;
+    uint64_t np = 0;
+    check(h, gams_wave_peaks(h, pg.p, &pk, &np));
+    uint64_t q = 0;
+    for (uint32_t c = 0; c < n; ++c) {                                  // wave.rs:169-211
+        uint64_t q1 = q;
+        while (q1 < np && pk[q1].ctg == c) ++q1;
+        // crests and troughs separately (:172-186)
+        std::vector<uint32_t> w[2];
+        std::vector<uint64_t> src[2];
+        for (uint64_t i = q; i < q1; ++i) {
+            const int s = pk[i].signal == 1 ? 0 : 1;
+            w[s].push_back(pk[i].window);
+            src[s].push_back(i);
+        }
+        std::vector<int64_t> cmin(q1 - q), cmax(q1 - q);
+        std::vector<char> merged(q1 - q, 0);
+        for (int s = 0; s < 2; ++s) {
+            Merge m = merge_ints(w[s], ctgs[c].chr_start, a.size, a.step, a.coverage);
+            for (size_t k = 0; k < w[s].size(); ++k) {
+                cmin[src[s][k] - q] = m.cmin[k];
+                cmax[src[s][k] - q] = m.cmax[k];
+                merged[src[s][k] - q] = m.in_graph[k];
+            }
+        }
+        std::string &o = out[c];
+        for (uint64_t i = q; i < q1; ++i) {                             // window order (:191)
+            const int64_t s = (int64_t)ctgs[c].chr_start + (int64_t)pk[i].window * a.step, e = s + a.size - 1;
+            if (merged[i - q]) {
+                // printed once, at the first member of the component (:201-206)
+                if (s != cmin[i - q]) continue;
+                o += ctgs[c].chr_id;
+                o += "(+):";
+                o += runlist(cmin[i - q], cmax[i - q]);
+            } else {
+                o += ctgs[c].chr_id;
+                o += ':';
+                o += runlist(s, e);
+            }
+            o += '\t';
+            o += fmt_f32((float)pk[i].gc_count / fsize);
+            o += '\t';
+            o += std::to_string(pk[i].signal);
+            o += '\n';
+        }
+        q = q1;
+    }
+    return out;
+}
+
+std::string wave_proc_ctg(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq, const WaveArgs &a) {
+    return wave_proc_ctgs(h, {ctg}, {seq}, a)[0];
+}
+
+// ---------------------------------------------------------------------------
+// sw
+// ---------------------------------------------------------------------------
+std::string sw_proc_ctg(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq, const std::vector<Feature> &features,
+                        const SwArgs &a) {
+    std::string out;
+    const uint32_t nf = (uint32_t)features.size();
+    if (nf == 0) return out;
+    uint32_t len = (uint32_t)(ctg.chr_end - ctg.chr_start + 1);
+    SeqSetGuard sg{h};
+    check(h, gams_seqset_create(h, 1, &len, &sg.s));
+    check(h, gams_seqset_upload(h, sg.s, 0, seq));
+    std::vector<int32_t> fs(nf), fe(nf);
+    for (uint32_t f = 0; f < nf; ++f) {
+        fs[f] = features[f].start;
+        fe[f] = features[f].end;
+    }
+    uint64_t nrows = 0;
+    check(h, gams_gpu_sw(h, sg.s, 0, ctg.chr_start, fs.data(), fe.data(), nf, a.size, a.max, a.resize, nullptr, 0,
+                         &nrows));
+    std::vector<gams_sw_row_t> rows(nrows ? nrows : 1);
+    check(h, gams_gpu_sw(h, sg.s, 0, ctg.chr_start, fs.data(), fe.data(), nf, a.size, a.max, a.resize,
+                         rows.data(), nrows, &nrows));
+    static const char *TYPES[3] = {"M", "L", "R"};
+    out.reserve(nrows * 80);
+    uint32_t cur = UINT32_MAX, sn = 0;
+    for (uint64_t r = 0; r < nrows; ++r) {                              // sw.rs:152-190
+        const gams_sw_row_t &w = rows[r];
+        if (w.feature != cur) {
+            cur = w.feature;
+            sn = 1;                                                     // sw.rs:148
+        }
+        out += "sw:";                                                   // sw.rs:153
+        out += features[w.feature].id;
+        out += ':';
+        out += std::to_string(sn++);
+        out += '\t';
+        out += ctg.chr_id;                                              // sw.rs:157 Range::from(chr, min, max)
+        out += ':';
+        out += runlist(w.start, w.end);
+        out += '\t';
+        out += TYPES[w.type];
+        out += '\t';
+        out += std::to_string(w.distance);
+        out += '\t';
+        out += fmt_f32(w.gc_content);                                   // data.rs:61-67
+        out += '\t';
+        out += fmt_f32(w.gc_mean);
+        out += '\t';
+        out += fmt_f32(w.gc_stddev);
+        out += '\t';
+        out += fmt_f32(w.gc_cv);
+        out += "\t\n";                                                  // empty rg_count (data.rs:71-80)
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------
+// locate
+// ---------------------------------------------------------------------------
+Locator::Locator(gams_gpu_t *h, const std::vector<Ctg> &ctgs) : h_(h), ctgs_(ctgs) {
+    // redis.rs:236-258: per chr a Lapper of (chr_start, chr_end + 1, ctg_id)
+    std::map<std::string, std::vector<uint32_t>> by_chr;
+    for (uint32_t i = 0; i < ctgs_.size(); ++i) {
+        by_chr[ctgs_[i].chr_id].push_back(i);
+        ctg_slot_[ctgs_[i].id] = i;
+    }
+    std::vector<uint64_t> off{0};
+    std::vector<uint32_t> st, sp;
+    std::vector<Ctg> ordered;
+    uint32_t g = 0;
+    for (auto &kv : by_chr) {
+        chr_group_[kv.first] = g++;
+        for (uint32_t i : kv.second) {
+            st.push_back((uint32_t)ctgs_[i].chr_start);
+            sp.push_back((uint32_t)ctgs_[i].chr_end + 1u);
+            ordered.push_back(ctgs_[i]);
+        }
+        off.push_back(st.size());
+    }
+    ctgs_ = ordered;  // hit indices refer to this order
+    ctg_slot_.clear();
+    for (uint32_t i = 0; i < ctgs_.size(); ++i) ctg_slot_[ctgs_[i].id] = i;
+    check(h_, gams_index_create(h_, g, off.data(), st.data(), sp.data(), &ctg_ix_));
+}
+
+Locator::~Locator() {
+    if (ctg_ix_) gams_index_destroy(h_, ctg_ix_);
+    if (rg_ix_) gams_index_destroy(h_, rg_ix_);
+}
+
+const Ctg *Locator::ctg(const std::string &id) const {
+    auto it = ctg_slot_.find(id);
+    return it == ctg_slot_.end() ? nullptr : &ctgs_[it->second];
+}
+
+void Locator::set_rg_index(const std::map<std::string, std::vector<Range>> &rg_of_ctg) {
+    if (rg_ix_) {
+        gams_index_destroy(h_, rg_ix_);
+        rg_ix_ = nullptr;
+    }
+    rg_group_.clear();
+    std::vector<uint64_t> off{0};
+    std::vector<uint32_t> st, sp;
+    uint32_t g = 0;
+    for (auto &kv : rg_of_ctg) {                                        // redis.rs:288-299
+        rg_group_[kv.first] = g++;
+        for (const Range &r : kv.second) {
+            st.push_back((uint32_t)r.start);
+            sp.push_back((uint32_t)r.end + 1u);
+        }
+        off.push_back(st.size());
+    }
+    check(h_, gams_index_create(h_, g, off.data(), st.data(), sp.data(), &rg_ix_));
+}
+
+std::vector<std::string> Locator::find(const std::vector<Range> &rgs) {
+    const uint64_t nq = rgs.size();
+    std::vector<uint32_t> grp(nq), qs(nq), qe(nq);
+    for (uint64_t i = 0; i < nq; ++i) {
+        auto it = chr_group_.find(rgs[i].chr);                          // utils.rs:11-13
+        grp[i] = it == chr_group_.end() ? UINT32_MAX : it->second;
+        qs[i] = (uint32_t)rgs[i].start;                                 // utils.rs:16: find(start, end)
+        qe[i] = (uint32_t)rgs[i].end;
+    }
+    std::vector<int64_t> hit(nq ? nq : 1);
+    check(h_, gams_gpu_locate(h_, ctg_ix_, grp.data(), qs.data(), qe.data(), nq, hit.data()));
+    std::vector<std::string> out(nq);
+    for (uint64_t i = 0; i < nq; ++i)
+        if (hit[i] >= 0) out[i] = ctgs_[(size_t)hit[i]].id;
+    return out;
+}
+
+std::string Locator::locate(const std::vector<std::string> &rgs, bool is_count) {
+    std::vector<Range> valid;
+    std::vector<size_t> src;
+    for (size_t i = 0; i < rgs.size(); ++i) {                           // locate.rs:111-116
+        Range r = Range::from_str(rgs[i]);
+        if (!r.valid) continue;
+        r.strand.clear();
+        valid.push_back(r);
+        src.push_back(i);
+    }
+    std::vector<std::string> ctg_ids = find(valid);
+    std::string out;
+    if (!is_count) {
+        for (size_t k = 0; k < valid.size(); ++k) {
+            if (ctg_ids[k].empty()) continue;                           // locate.rs:120-122
+            out += rgs[src[k]] + "\t" + ctg_ids[k] + "\n";             // locate.rs:139
+        }
+        return out;
+    }
+    if (!rg_ix_) throw Error(GAMS_ESTATE, "locate --count: no rg index loaded");
+    std::vector<uint32_t> grp, qs, qe;
+    std::vector<size_t> who;
+    for (size_t k = 0; k < valid.size(); ++k) {
+        if (ctg_ids[k].empty()) continue;
+        auto it = rg_group_.find(ctg_ids[k]);
+        if (it == rg_group_.end()) fprintf(stderr, "%s not found in idx\n", ctg_ids[k].c_str());  // utils.rs:30
+        grp.push_back(it == rg_group_.end() ? UINT32_MAX : it->second);
+        qs.push_back((uint32_t)valid[k].start);
+        qe.push_back((uint32_t)valid[k].end);
+        who.push_back(k);
+    }
+    std::vector<int32_t> cnt(who.size() ? who.size() : 1);
+    check(h_, gams_gpu_count(h_, rg_ix_, grp.data(), qs.data(), qe.data(), who.size(), cnt.data()));
+    for (size_t j = 0; j < who.size(); ++j)
+        out += rgs[src[who[j]]] + "\t" + std::to_string(cnt[j]) + "\n";  // locate.rs:137
+    return out;
+}
+
+// ---------------------------------------------------------------------------
+// anno
+// ---------------------------------------------------------------------------
+namespace {
+
+// utils.rs:118-129: first match of (?i)ctg:[\w_]+:\d+
+bool extract_ctg_id(const std::string &s, std::string &id) {
+    for (size_t i = 0; i + 4 <= s.size(); ++i) {
+        if ((s[i] == 'c' || s[i] == 'C') && (s[i + 1] == 't' || s[i + 1] == 'T') &&
+            (s[i + 2] == 'g' || s[i + 2] == 'G') && s[i + 3] == ':') {
+            size_t j = i + 4;
+            while (j < s.size() && is_word(s[j])) ++j;
+            if (j == i + 4 || j >= s.size() || s[j] != ':') continue;
+            size_t k = j + 1;
+            while (k < s.size() && s[k] >= '0' && s[k] <= '9') ++k;
+            if (k == j + 1) continue;
+            id = s.substr(i, k - i);
+            return true;
+        }
+    }
+    return false;
+}
+
+std::vector<std::string> split_tab(const std::string &s) {
+    std::vector<std::string> parts;
+    size_t b = 0;
+    for (;;) {
+        size_t e = s.find('\t', b);
+        if (e == std::string::npos) {
+            parts.push_back(s.substr(b));
+            break;
+        }
+        parts.push_back(s.substr(b, e - b));
+        b = e + 1;
+    }
+    return parts;
+}
+
+}  // namespace
+
+std::string anno(gams_gpu_t *h, const std::map<std::string, Runlist> &sets, const std::vector<Ctg> &ctgs,
+                 const std::vector<std::string> &lines, bool header, const std::string &prefix, size_t idx_id,
+                 size_t idx_range) {
+    std::map<std::string, const Ctg *> ctg_of;
+    for (const Ctg &c : ctgs) ctg_of[c.id] = &c;
+    // device image of the runlists: one group per chr
+    std::map<std::string, uint32_t> group_of;
+    std::vector<uint64_t> off{0};
+    std::vector<int32_t> lo, hi;
+    uint32_t g = 0;
+    for (auto &kv : sets) {
+        group_of[kv.first] = g++;
+        lo.insert(lo.end(), kv.second.lo.begin(), kv.second.lo.end());
+        hi.insert(hi.end(), kv.second.hi.begin(), kv.second.hi.end());
+        off.push_back(lo.size());
+    }
+    gams_spans_t *sp = nullptr;
+    check(h, gams_spans_create(h, g, off.data(), lo.data(), hi.data(), &sp));
+    struct Guard {
+        gams_gpu_t *h;
+        gams_spans_t *sp;
+        ~Guard() { gams_spans_destroy(h, sp); }
+    } guard{h, sp};
+
+    std::vector<size_t> keep;  // lines that produce a row
+    std::vector<uint32_t> grp;
+    std::vector<int32_t> cl, ch, qs, qe;
+    for (size_t i = 0; i < lines.size(); ++i) {                        // anno.rs:97
+        if (header && i == 0) continue;
+        std::vector<std::string> parts = split_tab(lines[i]);
+        if (idx_id == 0 || idx_range == 0 || idx_id > parts.size() || idx_range > parts.size())
+            throw Error(GAMS_EINVAL, "anno: field index out of range (the reference panics, anno.rs:115)");
+        std::string ctg_id;
+        if (!extract_ctg_id(parts[idx_id - 1], ctg_id)) continue;       // anno.rs:116-119
+        Range r = Range::from_str(parts[idx_range - 1]);
+        if (!r.valid) continue;                                         // anno.rs:123-125
+        auto gi = group_of.find(r.chr);
+        uint32_t gq = UINT32_MAX;
+        int32_t c0 = 0, c1 = 0;
+        if (gi != group_of.end()) {                                     // anno.rs:129
+            auto ci = ctg_of.find(ctg_id);
+            if (ci == ctg_of.end())
+                throw Error(GAMS_EINVAL, "anno: unknown " + ctg_id + " (the reference panics, redis.rs:133-134)");
+            gq = gi->second;
+            c0 = ci->second->chr_start;
+            c1 = ci->second->chr_end;
+        }
+        keep.push_back(i);
+        grp.push_back(gq);
+        cl.push_back(c0);
+        ch.push_back(c1);
+        qs.push_back(r.start);
+        qe.push_back(r.end);
+    }
+    std::vector<float> prop(keep.size() ? keep.size() : 1);
+    check(h, gams_gpu_cover(h, sp, grp.data(), cl.data(), ch.data(), qs.data(), qe.data(), keep.size(), prop.data()));
+    std::string out;
+    if (header && !lines.empty()) out += lines[0] + "\t" + prefix + "Prop\n";  // anno.rs:108
+    char buf[64];
+    for (size_t k = 0; k < keep.size(); ++k) {
+        snprintf(buf, sizeof buf, "%.4f", (double)prop[k]);             // anno.rs:140 {:.4}
+        out += lines[keep[k]] + "\t" + buf + "\n";
+    }
+    return out;
+}
+
+}  // namespace gams

@@ -1,0 +1,110 @@
+// gams_host.hpp -- C++17 host side of the hot path, above the C ABI (include/gams_gpu.h).
+//
+// The reference's host is Rust; no Rust toolchain exists in this image, so the host layer that
+// a Rust build would keep is written in C++ against the same extern "C" boundary.  It mirrors
+// the reference's seam fn(&Ctg, &ArgMatches) -> String (src/libs/utils.rs:216-220) for
+//   wave::proc_ctg   src/cmd_gams/wave.rs:121-215  (+ merge_ints :217-252)
+//   sw::proc_ctg     src/cmd_gams/sw.rs:108-194    (+ Sw Display, src/libs/data.rs:58-83)
+//   locate loop      src/cmd_gams/locate.rs:111-141
+//   anno loop        src/cmd_gams/anno.rs:95-142
+// Everything numeric runs on the GPU through libgams_gpu.so; this layer only keeps the
+// reference's bookkeeping: range grammar, peak merging, TSV text.
+#pragma once
+
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gams_gpu.h"
+
+namespace gams {
+
+// src/libs/data.rs:5-14
+struct Ctg {
+    std::string id;      // "ctg:{chr}:{serial}"
+    std::string range;   // "{chr}:{start}-{end}"
+    std::string chr_id;
+    int32_t chr_start = 0, chr_end = 0;
+    std::string chr_strand = "+";
+    int32_t length = 0;
+};
+
+// src/libs/data.rs:16-22 (only what sw needs)
+struct Feature {
+    std::string id;      // "feature:{ctg_id}:{serial}"
+    int32_t start = 0, end = 0;
+};
+
+// intspan::Range (chr(strand):start-end)
+struct Range {
+    std::string name, chr, strand;
+    int32_t start = 0, end = 0;
+    bool valid = false;
+    static Range from_str(const std::string &s);
+    std::string to_string() const;
+};
+
+// Rust `{}` for f32: shortest round-trip digits, positional
+std::string fmt_f32(float v);
+// IntSpan::runlist of one span
+std::string runlist(int64_t s, int64_t e);
+
+struct WaveArgs {          // defaults of src/cmd_gams/wave.rs:23-99
+    int32_t size = 100, step = 10;
+    uint32_t lag = 100;
+    float threshold = 3.0f, influence = 1.0f, coverage = 0.2f;
+    bool signal = false;
+};
+
+struct SwArgs {            // defaults of src/cmd_gams/sw.rs:9-85
+    int32_t size = 100, max = 20, resize = 500;
+};
+
+class Error : public std::runtime_error {
+public:
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+// wave.rs:121-215 for a batch of ctgs in ONE device pass; returns one String per ctg
+std::vector<std::string> wave_proc_ctgs(gams_gpu_t *h, const std::vector<Ctg> &ctgs,
+                                        const std::vector<const uint8_t *> &seqs, const WaveArgs &a);
+std::string wave_proc_ctg(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq, const WaveArgs &a);
+
+// sw.rs:108-194
+std::string sw_proc_ctg(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq, const std::vector<Feature> &features,
+                        const SwArgs &a);
+
+// idx:ctg: / idx:rg: on the device (redis.rs:236-324) + the locate loop (locate.rs:111-141)
+class Locator {
+public:
+    Locator(gams_gpu_t *h, const std::vector<Ctg> &ctgs);
+    ~Locator();
+    // idx:rg:{ctg}: ranges already bucketed per ctg (rg loader, utils.rs:39-67)
+    void set_rg_index(const std::map<std::string, std::vector<Range>> &rg_of_ctg);
+    // find_one_idx for every range; "" when not located (utils.rs:7-22)
+    std::vector<std::string> find(const std::vector<Range> &rgs);
+    // locate output: "{rg}\t{ctg_id}\n" or with count "{rg}\t{count}\n" (locate.rs:135-140)
+    std::string locate(const std::vector<std::string> &rgs, bool is_count);
+    const Ctg *ctg(const std::string &id) const;
+
+private:
+    gams_gpu_t *h_;
+    std::vector<Ctg> ctgs_;                       // in index order
+    std::map<std::string, uint32_t> chr_group_;   // chr -> group of the ctg index
+    std::map<std::string, uint32_t> ctg_slot_;    // ctg id -> position in ctgs_
+    gams_index_t *ctg_ix_ = nullptr;
+    gams_index_t *rg_ix_ = nullptr;
+    std::map<std::string, uint32_t> rg_group_;    // ctg id -> group of the rg index
+};
+
+// anno.rs:95-142; `sets` = runlists per chr (sorted disjoint spans)
+struct Runlist {
+    std::vector<int32_t> lo, hi;
+};
+std::string anno(gams_gpu_t *h, const std::map<std::string, Runlist> &sets, const std::vector<Ctg> &ctgs,
+                 const std::vector<std::string> &lines, bool header, const std::string &prefix, size_t idx_id,
+                 size_t idx_range);
+
+}  // namespace gams

@@ -115,6 +115,13 @@ int gams_wave_dense(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t i,
  * windows of the last run took the exact-order f32 re-evaluation. */
 int gams_wave_plan_set_tile(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tile_windows);
 int gams_wave_exact_count(gams_gpu_t *h, gams_wave_plan_t *p, uint64_t *n_exact);
+/* Diagnostics: with stamps on, thread 0 of every workgroup records the shader clock at the
+ * kernel's phase boundaries.  mean_cycles[0..5] = mean duration of load+classify, chunk
+ * prefix, window counts, z-score, exact re-evaluation, outputs; [6] = whole workgroup;
+ * span_cycles = first workgroup start to last workgroup end. */
+int gams_wave_plan_set_stamps(gams_gpu_t *h, gams_wave_plan_t *p, int enable);
+int gams_wave_stamps(gams_gpu_t *h, gams_wave_plan_t *p, double *mean_cycles /* [8] */,
+                     uint64_t *span_cycles);
 
 /* Convenience, one ctg from host memory (what wave.rs:143-155 computes):
  * gc_count / signal receive n = gams_window_count(len,size,step) items. */

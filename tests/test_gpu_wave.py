@@ -125,7 +125,7 @@ def test_batch_peaks_ordered_and_exact(eng, s288c):
     # several ctgs of ragged length in one launch; peaks must come back in (ctg, window) order
     seqs = [s288c["I"][:100000], s288c["I"][100000:], s288c["Mito"], synth(333333, 5), synth(5000, 6)]
     ss = engine.SeqSet(eng, seqs)
-    for tile in (0, 256, 1024, 8192):
+    for tile in (0, 256, 1024, 3072, 5120, 8192):
         plan = engine.WavePlan(eng, ss, 100, 10, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS | _lib.WAVE_DENSE,
                                tile_windows=tile)
         plan.run()
