@@ -1,0 +1,123 @@
+"""ctypes binding of libgams_host.so: the C++ host layer (gams_amd/host/*.cpp) that mirrors the
+reference's per-ctg operators (wave/sw proc_ctg, locate, anno) on top of the C ABI."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libgams_host.so")
+_h = None
+
+
+class HostError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gams host error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    global _h
+    if _h is not None:
+        return _h
+    _lib.load()
+    if not os.path.exists(SO_PATH):
+        raise ImportError(f"{SO_PATH} is missing: run __graft_entry__.build()")
+    L = C.CDLL(SO_PATH)
+    sp = C.POINTER(C.c_char_p)
+    ip = C.c_void_p
+    L.gams_host_last_error.restype = C.c_char_p
+    L.gams_host_last_code.restype = C.c_int
+    L.gams_host_free.argtypes = [C.c_void_p]
+    L.gams_host_wave.restype = C.c_void_p
+    L.gams_host_wave.argtypes = [C.c_void_p, C.c_uint32, sp, sp, ip, ip, C.POINTER(C.c_void_p), C.c_int32,
+                                 C.c_int32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_int]
+    L.gams_host_sw.restype = C.c_void_p
+    L.gams_host_sw.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint32,
+                               sp, ip, ip, C.c_int32, C.c_int32, C.c_int32]
+    L.gams_host_locate.restype = C.c_void_p
+    L.gams_host_locate.argtypes = [C.c_void_p, C.c_uint32, sp, sp, ip, ip, C.c_char_p, C.c_int, C.c_char_p]
+    L.gams_host_find.restype = C.c_void_p
+    L.gams_host_find.argtypes = [C.c_void_p, C.c_uint32, sp, sp, ip, ip, C.c_char_p]
+    L.gams_host_anno.restype = C.c_void_p
+    L.gams_host_anno.argtypes = [C.c_void_p, C.c_uint32, sp, sp, ip, ip, C.c_char_p, C.c_char_p, C.c_int,
+                                 C.c_char_p, C.c_uint32, C.c_uint32]
+    L.gams_host_fmt_f32.restype = C.c_void_p
+    L.gams_host_fmt_f32.argtypes = [C.c_float]
+    L.gams_host_range_roundtrip.restype = C.c_void_p
+    L.gams_host_range_roundtrip.argtypes = [C.c_char_p]
+    _h = L
+    return L
+
+
+def _take(p):
+    L = load()
+    if not p:
+        raise HostError(L.gams_host_last_code(), L.gams_host_last_error().decode(errors="replace"))
+    s = C.string_at(p).decode()
+    L.gams_host_free(p)
+    return s
+
+
+def _ctg_arrays(ctgs):
+    n = len(ctgs)
+    ids = (C.c_char_p * max(n, 1))(*[c["id"].encode() for c in ctgs])
+    chrs = (C.c_char_p * max(n, 1))(*[c["chr_id"].encode() for c in ctgs])
+    st = np.array([c["chr_start"] for c in ctgs], np.int32)
+    en = np.array([c["chr_end"] for c in ctgs], np.int32)
+    return n, ids, chrs, st, en
+
+
+def wave(eng, ctgs, size=100, step=10, lag=100, threshold=3.0, influence=1.0, coverage=0.2, is_signal=False):
+    """TSV rows (no header) of `gams wave` over `ctgs` (dicts with id, chr_id, chr_start, chr_end, seq)."""
+    n, ids, chrs, st, en = _ctg_arrays(ctgs)
+    bufs = [np.ascontiguousarray(np.frombuffer(c["seq"], np.uint8) if not isinstance(c["seq"], np.ndarray)
+                                 else c["seq"]) for c in ctgs]
+    seqs = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in bufs])
+    return _take(load().gams_host_wave(eng.h, n, ids, chrs, st.ctypes.data, en.ctypes.data, seqs, size, step, lag,
+                                       threshold, influence, coverage, int(is_signal)))
+
+
+def sw(eng, ctg, features, size=100, mx=20, resize=500):
+    """features: list of (feature_id, start, end)."""
+    nf = len(features)
+    fid = (C.c_char_p * max(nf, 1))(*[f[0].encode() for f in features])
+    fs = np.array([f[1] for f in features], np.int32)
+    fe = np.array([f[2] for f in features], np.int32)
+    seq = np.ascontiguousarray(np.frombuffer(ctg["seq"], np.uint8) if not isinstance(ctg["seq"], np.ndarray)
+                               else ctg["seq"])
+    return _take(load().gams_host_sw(eng.h, ctg["id"].encode(), ctg["chr_id"].encode(), ctg["chr_start"],
+                                     ctg["chr_end"], seq.ctypes.data, nf, fid, fs.ctypes.data, fe.ctypes.data,
+                                     size, mx, resize))
+
+
+def locate(eng, ctgs, rgs, count=False, rg_records=()):
+    """rgs: list of range strings; rg_records: list of (ctg_id, range string) for --count."""
+    n, ids, chrs, st, en = _ctg_arrays(ctgs)
+    rg_lines = "\n".join(f"{c}\t{r}" for c, r in rg_records)
+    return _take(load().gams_host_locate(eng.h, n, ids, chrs, st.ctypes.data, en.ctypes.data,
+                                         "\n".join(rgs).encode(), int(count), rg_lines.encode()))
+
+
+def find(eng, ctgs, rgs):
+    n, ids, chrs, st, en = _ctg_arrays(ctgs)
+    out = _take(load().gams_host_find(eng.h, n, ids, chrs, st.ctypes.data, en.ctypes.data, "\n".join(rgs).encode()))
+    return out.split("\n")[:len(rgs)]
+
+
+def anno(eng, ctgs, runlists, lines, header=False, prefix="", idx_id=1, idx_range=2):
+    """runlists: dict chr -> runlist string."""
+    n, ids, chrs, st, en = _ctg_arrays(ctgs)
+    rl = "\n".join(f"{k}\t{v}" for k, v in runlists.items())
+    return _take(load().gams_host_anno(eng.h, n, ids, chrs, st.ctypes.data, en.ctypes.data, rl.encode(),
+                                       "\n".join(lines).encode(), int(header), prefix.encode(), idx_id, idx_range))
+
+
+def fmt_f32(v):
+    return _take(load().gams_host_fmt_f32(v))
+
+
+def range_roundtrip(s):
+    return _take(load().gams_host_range_roundtrip(s.encode()))

@@ -44,9 +44,34 @@ struct PlanGuard {
 std::string fmt_f32(float v) {
     if (std::isnan(v)) return "NaN";
     if (std::isinf(v)) return v < 0 ? "-inf" : "inf";
-    char buf[128];
-    auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::fixed);  // shortest round trip
-    return std::string(buf, r.ptr);
+    if (v == 0.0f) return std::signbit(v) ? "-0" : "0";
+    // shortest round-trip digits (Ryu-style, like Rust), then positional notation
+    char buf[64];
+    auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::scientific);
+    std::string sci(buf, r.ptr);           // [-]d[.ddd]e[+-]XX
+    std::string out;
+    size_t i = 0;
+    if (sci[0] == '-') {
+        out += '-';
+        i = 1;
+    }
+    std::string digits;
+    for (; i < sci.size() && sci[i] != 'e'; ++i)
+        if (sci[i] != '.') digits += sci[i];
+    const int ex = std::atoi(sci.c_str() + i + 1);
+    const int nd = (int)digits.size();
+    if (ex >= 0) {
+        for (int k = 0; k <= ex; ++k) out += k < nd ? digits[k] : '0';
+        if (nd > ex + 1) {
+            out += '.';
+            out.append(digits, ex + 1, std::string::npos);
+        }
+    } else {
+        out += "0.";
+        out.append((size_t)(-ex - 1), '0');
+        out += digits;
+    }
+    return out;
 }
 
 std::string runlist(int64_t s, int64_t e) {

@@ -1,0 +1,175 @@
+// gams_host_c.cpp -- flat C entry points of the host layer, for tests (ctypes) and for a
+// non-C++ host.  Strings returned are malloc'd: release with gams_host_free.  On error the
+// functions return NULL and gams_host_last_error() has the message.
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+
+#include "gams_host.hpp"
+
+namespace {
+thread_local std::string g_err;
+thread_local int g_code = 0;
+
+char *dup(const std::string &s) {
+    char *p = (char *)std::malloc(s.size() + 1);
+    if (p) std::memcpy(p, s.c_str(), s.size() + 1);
+    return p;
+}
+
+template <typename F>
+char *guarded(F &&f) {
+    try {
+        g_err.clear();
+        g_code = 0;
+        return dup(f());
+    } catch (const gams::Error &e) {
+        g_err = e.what();
+        g_code = e.code;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        g_code = -1;
+    }
+    return nullptr;
+}
+
+std::vector<gams::Ctg> make_ctgs(uint32_t n, const char *const *ids, const char *const *chrs, const int32_t *starts,
+                                 const int32_t *ends) {
+    std::vector<gams::Ctg> v(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        v[i].id = ids[i];
+        v[i].chr_id = chrs[i];
+        v[i].chr_start = starts[i];
+        v[i].chr_end = ends[i];
+        v[i].length = ends[i] - starts[i] + 1;
+        v[i].range = v[i].chr_id + ":" + gams::runlist(starts[i], ends[i]);
+    }
+    return v;
+}
+
+std::vector<std::string> split_lines(const char *text) {
+    std::vector<std::string> lines;
+    std::istringstream is(text ? text : "");
+    std::string ln;
+    while (std::getline(is, ln)) lines.push_back(ln);
+    return lines;
+}
+}  // namespace
+
+extern "C" {
+
+const char *gams_host_last_error() { return g_err.c_str(); }
+int gams_host_last_code() { return g_code; }
+void gams_host_free(void *p) { std::free(p); }
+
+// wave.rs:121-215 over n ctgs in one device pass; the per-ctg Strings are concatenated in ctg order
+char *gams_host_wave(gams_gpu_t *h, uint32_t n, const char *const *ids, const char *const *chrs,
+                     const int32_t *starts, const int32_t *ends, const uint8_t *const *seqs, int32_t size,
+                     int32_t step, uint32_t lag, float threshold, float influence, float coverage, int is_signal) {
+    return guarded([&] {
+        gams::WaveArgs a;
+        a.size = size;
+        a.step = step;
+        a.lag = lag;
+        a.threshold = threshold;
+        a.influence = influence;
+        a.coverage = coverage;
+        a.signal = is_signal != 0;
+        std::vector<const uint8_t *> sp(seqs, seqs + n);
+        std::string out;
+        for (auto &s : gams::wave_proc_ctgs(h, make_ctgs(n, ids, chrs, starts, ends), sp, a)) out += s;
+        return out;
+    });
+}
+
+// sw.rs:108-194 for one ctg
+char *gams_host_sw(gams_gpu_t *h, const char *ctg_id, const char *chr, int32_t chr_start, int32_t chr_end,
+                   const uint8_t *seq, uint32_t nf, const char *const *feature_ids, const int32_t *fs,
+                   const int32_t *fe, int32_t size, int32_t max, int32_t resize) {
+    return guarded([&] {
+        const char *ids[1] = {ctg_id}, *chrs[1] = {chr};
+        gams::Ctg c = make_ctgs(1, ids, chrs, &chr_start, &chr_end)[0];
+        std::vector<gams::Feature> f(nf);
+        for (uint32_t i = 0; i < nf; ++i) f[i] = gams::Feature{feature_ids[i], fs[i], fe[i]};
+        gams::SwArgs a;
+        a.size = size;
+        a.max = max;
+        a.resize = resize;
+        return gams::sw_proc_ctg(h, c, seq, f, a);
+    });
+}
+
+// locate.rs:111-141.  rgs: newline-separated ranges (first TSV column already cut).
+// rg_lines (for --count): newline-separated "ctg_id\trange" rows = the rg: records per ctg.
+char *gams_host_locate(gams_gpu_t *h, uint32_t n, const char *const *ids, const char *const *chrs,
+                       const int32_t *starts, const int32_t *ends, const char *rgs, int is_count,
+                       const char *rg_lines) {
+    return guarded([&] {
+        gams::Locator loc(h, make_ctgs(n, ids, chrs, starts, ends));
+        if (is_count) {
+            std::map<std::string, std::vector<gams::Range>> rg_of;
+            for (uint32_t i = 0; i < n; ++i) rg_of[ids[i]];  // build_idx_rg visits every ctg (redis.rs:279-302)
+            for (const std::string &ln : split_lines(rg_lines)) {
+                size_t tab = ln.find('\t');
+                if (tab == std::string::npos) continue;
+                gams::Range r = gams::Range::from_str(ln.substr(tab + 1));
+                if (r.valid) rg_of[ln.substr(0, tab)].push_back(r);
+            }
+            loc.set_rg_index(rg_of);
+        }
+        return loc.locate(split_lines(rgs), is_count != 0);
+    });
+}
+
+// utils.rs:7-22 for many ranges: one ctg id (or empty) per line
+char *gams_host_find(gams_gpu_t *h, uint32_t n, const char *const *ids, const char *const *chrs,
+                     const int32_t *starts, const int32_t *ends, const char *rgs) {
+    return guarded([&] {
+        gams::Locator loc(h, make_ctgs(n, ids, chrs, starts, ends));
+        std::vector<gams::Range> v;
+        for (const std::string &ln : split_lines(rgs)) {
+            gams::Range r = gams::Range::from_str(ln);
+            r.strand.clear();
+            if (!r.valid) r.chr = "\x01invalid";  // never located
+            v.push_back(r);
+        }
+        std::string out;
+        for (const std::string &id : loc.find(v)) out += id + "\n";
+        return out;
+    });
+}
+
+// anno.rs:95-142.  runlists: newline-separated "chr\trunlist" rows of the JSON set.
+char *gams_host_anno(gams_gpu_t *h, uint32_t n, const char *const *ids, const char *const *chrs,
+                     const int32_t *starts, const int32_t *ends, const char *runlists, const char *lines,
+                     int header, const char *prefix, uint32_t idx_id, uint32_t idx_range) {
+    return guarded([&] {
+        std::map<std::string, gams::Runlist> sets;
+        for (const std::string &ln : split_lines(runlists)) {
+            size_t tab = ln.find('\t');
+            if (tab == std::string::npos) continue;
+            gams::Runlist &rl = sets[ln.substr(0, tab)];
+            std::istringstream is(ln.substr(tab + 1));
+            std::string part;
+            while (std::getline(is, part, ',')) {
+                if (part.empty() || part == "-") continue;
+                size_t dash = part.find('-', 1);
+                int32_t lo = std::atoi(part.substr(0, dash).c_str());
+                int32_t hi = dash == std::string::npos ? lo : std::atoi(part.substr(dash + 1).c_str());
+                rl.lo.push_back(lo);
+                rl.hi.push_back(hi);
+            }
+        }
+        return gams::anno(h, sets, make_ctgs(n, ids, chrs, starts, ends), split_lines(lines), header != 0,
+                          prefix ? prefix : "", idx_id, idx_range);
+    });
+}
+
+// formatting helpers exposed for CPU-only tests
+char *gams_host_fmt_f32(float v) { return dup(gams::fmt_f32(v)); }
+char *gams_host_range_roundtrip(const char *s) {
+    gams::Range r = gams::Range::from_str(s);
+    return dup(r.valid ? r.to_string() : std::string("<invalid>"));
+}
+
+}  // extern "C"

@@ -1,0 +1,250 @@
+"""GPU parity of the host operators (C++ layer over the C ABI) against the oracle's TSV text and
+the reference's golden fixtures: wave (merge + rows), sw, locate, locate --count, anno.
+These read like the reference's own CLI tests (tests/cli.rs) because the operators mirror it."""
+import numpy as np
+import pytest
+
+import helpers
+from gams_amd import engine, host
+from oracle import oracle as ora
+
+pytestmark = pytest.mark.gpu
+
+HEADER = "#range\tgc_content\tsignal\n"
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = engine.Engine(0)
+    yield e
+    e.close()
+
+
+def all_ctgs(s288c, piece=100000):
+    ctgs = []
+    for chr_id in ("I", "Mito"):
+        ctgs += helpers.gen_ctgs(chr_id, s288c[chr_id], piece=piece)
+    return ctgs
+
+
+# ---- wave -------------------------------------------------------------------------------------
+def test_wave_golden_I_peaks(eng, s288c):
+    """README.md:155-163 -> tests/S288c/I.peaks.tsv, byte for byte."""
+    ctgs = helpers.gen_ctgs("I", s288c["I"], piece=500000)
+    out = HEADER + host.wave(eng, ctgs, 100, 10, 100, 3.0, 1.0, 0.2)
+    assert out == "\n".join(helpers.read_lines("I.peaks.tsv")) + "\n"
+
+
+def test_command_wave(eng, s288c):
+    """tests/cli.rs:332-364."""
+    ctgs = helpers.gen_ctgs("I", s288c["I"], piece=100000)
+    out = HEADER + host.wave(eng, ctgs)
+    assert len(out.splitlines()) == 116
+    assert "I:7551-7650\t" in out
+    assert "I(+):11551-11740\t" in out
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),
+    dict(is_signal=True),
+    dict(coverage=1.0),
+    dict(coverage=1.5),            # only small overlaps link (size/|overlap| >= 1.5)
+    dict(coverage=5.0),
+    dict(coverage=50.0),
+    dict(size=100, step=1, lag=100),
+    dict(size=100, step=1, lag=100, coverage=2.0),
+    dict(size=50, step=7, lag=33, threshold=2.5, coverage=0.2),
+    dict(size=300, step=10, lag=250),
+    dict(influence=0.5),
+    dict(influence=0.0, threshold=2.0),
+])
+def test_wave_rows_equal_oracle(eng, s288c, kw):
+    ctgs = all_ctgs(s288c)
+    got = host.wave(eng, ctgs, **kw)
+    exp = "".join(ora.wave_proc_ctg(c["chr_id"], c["chr_start"], c["chr_end"], c["seq"], **kw) for c in ctgs)
+    assert got == exp
+
+
+def test_wave_short_ctg_reports_the_reference_panic(eng):
+    c = dict(id="ctg:X:1", chr_id="X", chr_start=1, chr_end=400, seq=b"ACGT" * 100)
+    with pytest.raises(host.HostError) as ei:
+        host.wave(eng, [c])
+    assert ei.value.code == 5  # GAMS_ESHORT
+
+
+# ---- sw ---------------------------------------------------------------------------------------
+def bucket_features(s288c, ctgs):
+    idx = helpers.ctg_index(ctgs)
+    buckets = {}
+    for ln in helpers.read_lines("spo11_hot.rg"):
+        chr_id, s, e = helpers.parse_range(ln)
+        hit = [i for i in idx.get(chr_id, []) if i[0] < e and i[1] > s]
+        if not hit:
+            continue
+        cid = hit[0][2]
+        if cid in buckets:
+            buckets[cid].append((s, e))
+        else:
+            buckets[cid] = []          # utils.rs:60-63: the first range only creates the bucket
+    return buckets
+
+
+def test_command_sw(eng, s288c):
+    """tests/cli.rs:306-330 (structure) + every numeric field against the oracle."""
+    ctgs = all_ctgs(s288c)
+    buckets = bucket_features(s288c, ctgs)
+    assert sum(len(v) for v in buckets.values()) == 69
+    out = ""
+    for c in sorted(ctgs, key=lambda c: c["id"]):
+        feats = [(f"feature:{c['id']}:{i + 1}", s, e) for i, (s, e) in enumerate(buckets.get(c["id"], []))]
+        got = host.sw(eng, c, feats) if feats else ""
+        exp = ora.sw_proc_ctg(c["chr_id"], c["chr_start"], c["chr_end"], c["seq"], feats)
+        assert got == exp
+        out += got
+    rows = out.splitlines()
+    assert len(rows) > 2000
+    assert any(r.startswith("sw:feature:ctg:I:2:32:1\t") for r in rows)
+
+
+@pytest.mark.parametrize("size,mx,resize", [(100, 20, 500), (100, 1, 100), (50, 5, 333), (10, 40, 5000), (100, 0, 500),
+                                            (200, 3, 100)])
+def test_sw_random_features(eng, s288c, size, mx, resize):
+    c = helpers.gen_ctgs("I", s288c["I"], piece=100000)[1]      # I:100001-230218
+    rng = np.random.default_rng(size * 1000 + mx)
+    feats = []
+    for i in range(300):
+        s = int(rng.integers(c["chr_start"], c["chr_end"] + 1))
+        e = min(c["chr_end"], s + int(rng.choice([0, 0, 1, 2, 99, 100, 101, 1500])))
+        feats.append((f"feature:{c['id']}:{i + 1}", s, e))
+    # ctg edges: clipping of M, missing L / R windows
+    feats += [(f"feature:{c['id']}:e{k}", p, p) for k, p in enumerate(
+        [c["chr_start"], c["chr_start"] + 1, c["chr_start"] + 49, c["chr_start"] + 50, c["chr_start"] + 99,
+         c["chr_start"] + 100, c["chr_end"], c["chr_end"] - 1, c["chr_end"] - 49, c["chr_end"] - 50,
+         c["chr_end"] - 99, c["chr_end"] - 100])]
+    got = host.sw(eng, c, feats, size, mx, resize)
+    exp = ora.sw_proc_ctg(c["chr_id"], c["chr_start"], c["chr_end"], c["seq"], feats, size, mx, resize)
+    assert got == exp
+
+
+# ---- locate -----------------------------------------------------------------------------------
+def test_command_locate(eng, s288c):
+    """tests/cli.rs:384-424."""
+    ctgs = all_ctgs(s288c)
+    out = host.locate(eng, ctgs, ["I:1000-1100", "II:1000-1100", "Mito:1000-1100"])
+    assert out == "I:1000-1100\tctg:I:1\nMito:1000-1100\tctg:Mito:1\n"
+    out = host.locate(eng, ctgs, helpers.read_lines("spo11_hot.rg"))
+    assert len(out.splitlines()) == 71
+    assert "ctg:I:1" in out and "ctg:Mito:1" not in out
+
+
+def rg_records(eng, ctgs, name):
+    """the rg loader (utils.rs:39-67 via cmd_gams/rg.rs:41-77) incl. the drop-first quirk"""
+    lines = helpers.read_lines(name)
+    ids = host.find(eng, ctgs, [ln.split("\t")[0] for ln in lines])
+    seen, recs = set(), []
+    for ln, cid in zip(lines, ids):
+        if not cid:
+            continue
+        if cid in seen:
+            recs.append((cid, ln.split("\t")[0]))
+        seen.add(cid)
+    return recs
+
+
+def test_command_rg_counts(eng, s288c):
+    """tests/cli.rs:235-253: 'There are 69 rgs in this file'."""
+    assert len(rg_records(eng, all_ctgs(s288c), "spo11_hot.rg")) == 69
+
+
+def test_command_locate_count(eng, s288c):
+    """tests/cli.rs:426-454."""
+    ctgs = all_ctgs(s288c)
+    recs = rg_records(eng, ctgs, "SK1.snp.rg")
+    out = host.locate(eng, ctgs, ["I:1000-2000", "II:1001-2000", "Mito:1000-2000"], count=True, rg_records=recs)
+    assert out == "I:1000-2000\t12\nMito:1000-2000\t0\n"
+
+
+def test_locate_and_count_random_vs_oracle(eng):
+    """overlapping stored intervals, point queries on interval edges, queries across ctgs"""
+    rng = np.random.default_rng(42)
+    ctgs, pos = [], 1
+    for k in range(40):                               # one chromosome, 40 ctgs with gaps
+        ln = int(rng.integers(5000, 60000))
+        ctgs.append(dict(id=f"ctg:1:{k + 1}", chr_id="1", chr_start=pos, chr_end=pos + ln - 1, seq=b""))
+        pos += ln + int(rng.integers(0, 3000))
+    qs = rng.integers(1, pos + 1000, 5000)
+    qe = qs + rng.choice([0, 0, 1, 10, 500, 70000], 5000)
+    qs[:40] = [c["chr_start"] for c in ctgs]         # point range on a ctg start: not located (a-16)
+    qe[:40] = qs[:40]
+    rgs = [f"1:{s}-{e}" if e != s else f"1:{s}" for s, e in zip(qs, qe)]
+    starts = np.array([c["chr_start"] for c in ctgs], np.uint32)
+    stops = np.array([c["chr_end"] + 1 for c in ctgs], np.uint32)
+    got = host.find(eng, ctgs, rgs)
+    for r, s, e, g in zip(rgs, qs, qe, got):
+        k = ora.lapper_find_first(starts, stops, int(s), int(e))
+        assert g == (ctgs[k]["id"] if k >= 0 else ""), r
+    assert all(g == "" for g in got[:40])
+    # --count against stored intervals of mixed lengths inside each ctg
+    recs, per_ctg = [], {}
+    for c in ctgs:
+        n = int(rng.integers(0, 400))
+        a = rng.integers(c["chr_start"], c["chr_end"] + 1, n)
+        b = np.minimum(a + rng.choice([0, 0, 0, 5, 300], n), c["chr_end"])
+        per_ctg[c["id"]] = (np.sort(a.astype(np.uint32)), np.sort((b + 1).astype(np.uint32)))
+        recs += [(c["id"], f"1:{x}-{y}" if y != x else f"1:{x}") for x, y in zip(a, b)]
+    out = host.locate(eng, ctgs, rgs, count=True, rg_records=recs).splitlines()
+    exp = []
+    for r, s, e, g in zip(rgs, qs, qe, got):
+        if g:
+            st, sp = per_ctg[g]
+            exp.append(f"{r}\t{ora.lapper_count(st, sp, int(s), int(e))}")
+    assert out == exp
+
+
+# ---- anno -------------------------------------------------------------------------------------
+def test_command_anno(eng, s288c):
+    """tests/cli.rs:456-481."""
+    ctgs = all_ctgs(s288c)
+    import json
+    import os
+
+    with open(os.path.join(helpers.S288C, "intergenic.json")) as fh:
+        runlists = json.load(fh)
+    lines = helpers.read_lines("ctg.range.tsv")
+    out = host.anno(eng, ctgs, runlists, lines, header=True, prefix="intergenic", idx_id=1, idx_range=2)
+    rows = out.splitlines()
+    assert len(rows) == 4 and len(rows[0].split("\t")) == 8
+    assert rows[0].endswith("\tintergenicProp")
+    assert "85779\t0.0000" in out and "130218\t0.1072" in out
+
+
+def test_anno_random_vs_oracle(eng):
+    rng = np.random.default_rng(9)
+    ctgs = [dict(id="ctg:1:1", chr_id="1", chr_start=1, chr_end=400000, seq=b""),
+            dict(id="ctg:1:2", chr_id="1", chr_start=400001, chr_end=900000, seq=b""),
+            dict(id="ctg:2:1", chr_id="2", chr_start=1001, chr_end=500000, seq=b"")]
+    sets = {}
+    for chr_id in ("1", "2"):
+        cuts = np.sort(rng.choice(np.arange(1, 950000), 4000, replace=False))
+        lo, hi = cuts[0::2], cuts[1::2] - 1
+        keep = hi >= lo
+        sets[chr_id] = (lo[keep].astype(np.int32), hi[keep].astype(np.int32))
+    runlists = {k: ",".join(f"{a}-{b}" if a != b else f"{a}" for a, b in zip(*v)) for k, v in sets.items()}
+    lines, exp = [], []
+    for i in range(3000):
+        c = ctgs[int(rng.integers(0, 3))]
+        s = int(rng.integers(max(1, c["chr_start"] - 500), c["chr_end"] + 500))
+        e = s + int(rng.choice([0, 1, 99, 5000, 200000]))
+        chr_id = c["chr_id"] if i % 50 else "3"                       # chr missing from the set -> 0.0000
+        rg = f"{chr_id}:{s}-{e}" if e != s else f"{chr_id}:{s}"
+        line = f"sw:feature:{c['id']}:{i}:1\t{rg}\tx"
+        lines.append(line)
+        prop = 0.0
+        if chr_id in sets:
+            lo, hi = sets[chr_id]
+            prop = ora.anno_prop(lo, hi, c["chr_start"], c["chr_end"], s, e)
+        exp.append(f"{line}\t{prop:.4f}")
+    lines.insert(7, "no contig id here\t1:5-9\tx")                     # dropped (anno.rs:116-119)
+    lines.insert(9, f"ctg:1:1\tnot_a_range\tx")                        # dropped (anno.rs:123-125)
+    out = host.anno(eng, ctgs, runlists, lines, header=False, idx_id=1, idx_range=2)
+    assert out.splitlines() == exp

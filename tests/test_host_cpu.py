@@ -1,0 +1,36 @@
+"""CPU-only checks of the C++ host layer's bookkeeping (formatting, range grammar)."""
+import numpy as np
+import pytest
+
+from gams_amd import host
+from oracle import oracle as ora
+
+
+def test_fmt_f32_matches_rust_display_and_the_oracle():
+    vals = [0.18, 0.3, 0.0, 1.0, 0.0816, 1e-7, 12.5, 100.0, 0.1633, 0.5, 123456.7, 3.4e38, 1.17e-38]
+    vals += [float(np.float32(k) / np.float32(100)) for k in range(101)]
+    vals += [float(np.float32(k) / np.float32(257)) for k in range(0, 257, 7)]
+    rng = np.random.default_rng(1)
+    vals += [float(x) for x in rng.random(500).astype(np.float32)]
+    vals += [float(np.round(np.float32(x) * 10000) / np.float32(10000)) for x in rng.random(200)]
+    for v in vals:
+        assert host.fmt_f32(v) == ora.fmt_f32(v), v
+    assert host.fmt_f32(float("nan")) == "NaN"
+    assert host.fmt_f32(float("inf")) == "inf"
+    assert host.fmt_f32(0.18) == "0.18" and host.fmt_f32(1.0) == "1" and host.fmt_f32(0.0) == "0"
+
+
+@pytest.mark.parametrize("s,exp", [
+    ("I:1000-1100", "I:1000-1100"),
+    ("I(+):11551-11740", "I(+):11551-11740"),
+    ("Mito:136", "Mito:136"),
+    ("S288c.I(-):27070-29557", "S288c.I(-):27070-29557"),
+    ("I:5-5", "I:5"),
+    ("I", "<invalid>"),
+    ("", "<invalid>"),
+    ("I:abc", "<invalid>"),
+    ("#range", "<invalid>"),
+    ("chr-1_x:1_200", "chr-1_x:1-200"),
+])
+def test_range_grammar(s, exp):
+    assert host.range_roundtrip(s) == exp
