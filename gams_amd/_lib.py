@@ -58,6 +58,7 @@ PROTOTYPES = {
     "gams_wave_exact_count": (C.c_int, [_VP, _VP, C.POINTER(C.c_uint64)]),
     "gams_wave_plan_set_stamps": (C.c_int, [_VP, _VP, C.c_int]),
     "gams_wave_stamps": (C.c_int, [_VP, _VP, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "gams_wave_stamps_raw": (C.c_int, [_VP, _VP, _VP, C.c_uint64]),
     "gams_gpu_wave": (C.c_int, [_VP, _VP, C.c_uint32, C.POINTER(WaveParams), _VP, _VP, C.POINTER(C.c_uint32)]),
     "gams_gpu_sw": (C.c_int, [_VP, _VP, C.c_uint32, C.c_int32, _VP, _VP, C.c_uint32, C.c_int32, C.c_int32,
                               C.c_int32, _VP, C.c_uint64, C.POINTER(C.c_uint64)]),

@@ -85,8 +85,19 @@ struct WaveArgs {
 // Phase stamp of a diagnostic run (gams_wave_plan_set_stamps): thread 0 of the
 // workgroup stores the shader clock.  Off (stamps == NULL) it is one scalar branch.
 __device__ __forceinline__ void wave_stamp(const WaveArgs &a, int slot) {
-    if (a.stamps != nullptr && threadIdx.x == 0)
-        a.stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_readcyclecounter();
+    if (a.stamps != nullptr && threadIdx.x == 0) {
+        // 16 words (one 128-B line) per workgroup: [0..6] shader clock at the phase
+        // boundaries, [8] / [9] the constant 100 MHz clock at workgroup start / end
+        a.stamps[(size_t)blockIdx.x * 16 + slot] = __builtin_readcyclecounter();
+        if (slot == 0) {
+            a.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memrealtime();
+            // where it ran: HW_ID (wave/simd/cu/sh/se) and XCC_ID
+            a.stamps[(size_t)blockIdx.x * 16 + 11] =
+                ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) |
+                (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        }
+        if (slot == 6) a.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // ---- G/C/g/c classification of 16 packed bytes -> 16-bit mask ------------------
@@ -328,24 +339,31 @@ __device__ __forceinline__ float readlane_f32(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
+// 64 sequential adds fed from the 64 lanes of `x` (constant lane numbers: no loop, no
+// scalar-register hazards beyond the readlane itself)
+__device__ __forceinline__ float seq_add_64(float acc, float x) {
+#pragma unroll
+    for (int l = 0; l < 64; ++l) acc = acc + readlane_f32(x, l);
+    return acc;
+}
+
 __device__ __noinline__ int exact_signal_wave(const uint8_t *K, uint32_t tj, uint32_t ti, uint32_t n,
                                               float fsize, float thr) {
     const uint32_t lane = threadIdx.x & 63u;
     const float len = (float)n;
+    // lanes past the end contribute +0.0f, which leaves an f32 sum of non-negative terms unchanged
     float sum = 0.0f;
     for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
-        const uint32_t m = min(64u, n - c0);
-        const float x = lane < m ? (float)K[tj + c0 + lane] / fsize : 0.0f;
-        for (uint32_t l = 0; l < m; ++l) sum = sum + readlane_f32(x, (int)l);   // stat.rs:3
+        const float x = c0 + lane < n ? (float)K[tj + c0 + lane] / fsize : 0.0f;
+        sum = seq_add_64(sum, x);                                                // stat.rs:3
     }
     const float mean = sum / len;                                                // stat.rs:5
     float sq = 0.0f;
     for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
-        const uint32_t m = min(64u, n - c0);
-        const float x = lane < m ? (float)K[tj + c0 + lane] / fsize : 0.0f;
+        const float x = (float)K[tj + min(c0 + lane, n - 1u)] / fsize;
         const float d = x - mean;
-        const float dd = d * d;
-        for (uint32_t l = 0; l < m; ++l) sq = sq + readlane_f32(dd, (int)l);    // stat.rs:12
+        const float dd = c0 + lane < n ? d * d : 0.0f;
+        sq = seq_add_64(sq, dd);                                                 // stat.rs:12
     }
     const float sd = sqrtf(sq / (len - 1.0f));                                   // stat.rs:13
     const float x = (float)K[ti] / fsize;
@@ -394,6 +412,8 @@ __global__ void wave_const_table_kernel(int8_t *const_sig, uint32_t size, uint32
 template <int W>
 __global__ __launch_bounds__(256) void wave_fast_kernel(const WaveArgs a) {
     static_assert(W % 4 == 0 && ((W / 4) & 1) == 1, "W/4 must be odd (LDS bank stride)");
+    if (a.stamps != nullptr && threadIdx.x == 0)
+        a.stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();  // workgroup entry
     constexpr uint32_t TW = 256u * W;
     constexpr int WD = W / 4;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -421,26 +441,20 @@ __global__ __launch_bounds__(256) void wave_fast_kernel(const WaveArgs a) {
 
     wave_stamp(a, 0);
     // ---- phase 1: load + classify ------------------------------------------
-    // Two batches of four 16-B loads stay in flight per thread: the next batch is
-    // issued before the current one is classified (one exposed HBM round trip per tile).
+    // Two batches of four 16-B loads stay in flight per thread: the next batch is issued
+    // before the current one is classified.  Loads and LDS stores are unconditional (index
+    // clamped to the last chunk / parked on the sentinel slot, which phase 1b rewrites):
+    // a predicated load sits in its own basic block and makes hipcc wait vmcnt(0).
     {
+        const uint32_t last = nchunk - 1u;
         uint4 cur[4], nxt[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t c = tid + 256u * k;
-            cur[k] = c < nchunk ? src[c] : make_uint4(0, 0, 0, 0);
-        }
+        for (int k = 0; k < 4; ++k) cur[k] = src[min(tid + 256u * k, last)];
         for (uint32_t c0 = tid; c0 < nchunk; c0 += 1024u) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t c = c0 + 1024u + 256u * k;
-                nxt[k] = c < nchunk ? src[c] : make_uint4(0, 0, 0, 0);
-            }
+            for (int k = 0; k < 4; ++k) nxt[k] = src[min(c0 + 1024u + 256u * k, last)];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t c = c0 + 256u * k;
-                if (c < nchunk) PM[c] = gc_mask16(cur[k]);
-            }
+            for (int k = 0; k < 4; ++k) PM[min(c0 + 256u * k, nchunk)] = gc_mask16(cur[k]);
 #pragma unroll
             for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
         }
@@ -486,14 +500,15 @@ __global__ __launch_bounds__(256) void wave_fast_kernel(const WaveArgs a) {
     const bool want_peaks = (a.flags & GAMS_WAVE_PEAKS) != 0;
     const bool want_dense = (a.flags & GAMS_WAVE_DENSE) != 0;
     const uint32_t base = tid * (uint32_t)W;        // K slot of the outgoing count of window q = 0
-    uint64_t sigbits = 0;                            // 2 bits per window: 1 crest, 3 trough
+    uint32_t crest = 0, trough = 0;                  // one bit per owned window
     uint32_t pend = 0;                               // windows whose decision sits inside the guard band
+    uint32_t in[WD + 1];                             // bytes K[base+lag .. base+lag+W]: incoming + own counts
     {
-        // Every thread runs this block (wave-uniform control flow): threads past the
-        // tile's last window read LDS inside the allocation and decide nothing.
+        // Every thread runs this block (wave-uniform control flow, no branches in the
+        // window loop): threads past the tile's last window read LDS inside the
+        // allocation and their decisions are masked off.
         const uint32_t bw = base >> 2;               // dword index (W % 4 == 0)
-        // outgoing counts K[base + q]
-        uint32_t og[WD];
+        uint32_t og[WD];                             // outgoing counts K[base + q]
 #pragma unroll
         for (int d = 0; d < WD; ++d) og[d] = KW[bw + d];
         // S1, S2 over K[base, base+lag)
@@ -511,8 +526,6 @@ __global__ __launch_bounds__(256) void wave_fast_kernel(const WaveArgs a) {
             S1 = __builtin_amdgcn_udot4(x, 0x01010101u, S1, false);
             S2 = __builtin_amdgcn_udot4(x, x, S2, false);
         }
-        // incoming/own run: bytes K[base+lag .. base+lag+W], realigned to dwords
-        uint32_t in[WD + 1];
         {
             const uint32_t ib = bw + nfull;
             uint32_t lo = KW[ib];
@@ -525,36 +538,72 @@ __global__ __launch_bounds__(256) void wave_fast_kernel(const WaveArgs a) {
         }
         const float thr_abs = a.thr_abs, cvar = a.cvar;
         const float g0 = a.g0, g1 = a.g1, g23 = a.g2 + a.g3;
+        // windows this thread may decide: inside the tile, i >= lag, signalling enabled
+        uint32_t can = 0;
+        if (!a.no_signal && base < nvalid) {
+            const uint32_t hi_q = min((uint32_t)W, nvalid - base);            // q < hi_q
+            const uint32_t lo_q = w0 + base >= lag ? 0u : min((uint32_t)W, lag - (w0 + base));  // q >= lo_q
+            can = ((1u << hi_q) - 1u) & ~((1u << lo_q) - 1u);
+        }
+        uint32_t decided = 0, isconst = 0;
 #pragma unroll
         for (int q = 0; q < W; ++q) {
             const uint32_t kout = (og[q >> 2] >> (8 * (q & 3))) & 0xFFu;
             const uint32_t kin = (in[q >> 2] >> (8 * (q & 3))) & 0xFFu;
             const uint32_t kk = (in[(q + 1) >> 2] >> (8 * ((q + 1) & 3))) & 0xFFu;
-            const uint32_t S1n = S1 + kin - kout;
-            const uint32_t S2n = S2 + __umul24(kin, kin) - __umul24(kout, kout);
-            const uint32_t i = w0 + base + q;
-            int sg = 0;
-            if (base + q < nvalid && i >= lag && !a.no_signal) {
-                const bool first = i == lag;         // averages windows [0,lag), like i == lag+1
-                const uint32_t s1 = first ? S1n : S1;
-                const uint32_t s2 = first ? S2n : S2;
-                const int32_t di = (int32_t)__umul24(lag, kk) - (int32_t)s1;
-                const uint32_t V = __umul24(lag, s2) - __umul24(s1, s1);
-                const float Df = fabsf((float)di);
-                const float Rf = thr_abs * __builtin_amdgcn_sqrtf(cvar * (float)V);
-                const float diff = Df - Rf;
-                const float G = __builtin_fmaf(g1, (float)s1, __builtin_fmaf(g23, Df + Rf, g0));
-                if (fabsf(diff) > G) {
-                    sg = diff > 0.0f ? (di > 0 ? 1 : -1) : 0;
-                } else if ((V | (uint32_t)di) == 0u) {
-                    sg = a.const_sig[kk];            // all lag counts and this one equal kk
-                } else {
-                    pend |= 1u << q;
-                }
+            const int32_t di = (int32_t)__umul24(lag, kk) - (int32_t)S1;   // sign: side of the mean
+            const uint32_t V = __umul24(lag, S2) - __umul24(S1, S1);       // n*S2 - S1^2 >= 0
+            const float Df = fabsf((float)di);
+            const float Rf = thr_abs * __builtin_amdgcn_sqrtf(cvar * (float)V);
+            const float diff = Df - Rf;
+            const float G = __builtin_fmaf(g1, (float)S1, __builtin_fmaf(g23, Df + Rf, g0));
+            const uint32_t bit = 1u << q;
+            decided |= fabsf(diff) > G ? bit : 0u;
+            isconst |= (V | (uint32_t)di) == 0u ? bit : 0u;                  // all lag counts equal kk
+            crest |= (diff > 0.0f && di > 0) ? bit : 0u;
+            trough |= (diff > 0.0f && di < 0) ? bit : 0u;
+            S1 += kin - kout;
+            S2 += __umul24(kin, kin) - __umul24(kout, kout);
+        }
+        // Window i == lag averages windows [0,lag) (stat.rs:30-31) like i == lag+1, not
+        // [i-1-lag, i-1): its owner (one thread per ctg) redoes the integer decision with the
+        // sums over K[base+qlag+1, base+qlag+1+lag).
+        const uint32_t qlag = lag - (w0 + base);                             // wraps when i == lag is not here
+        if (qlag < (uint32_t)W) {
+            const uint32_t bit = 1u << qlag;
+            uint32_t s1 = 0, s2 = 0;
+            for (uint32_t j = 0; j < lag; ++j) {
+                const uint32_t kv = K[base + qlag + 1u + j];
+                s1 += kv;
+                s2 += kv * kv;
             }
-            sigbits |= (uint64_t)(sg & 3) << (2 * q);
-            S1 = S1n;
-            S2 = S2n;
+            const uint32_t kk = K[base + qlag + lag + 1u];
+            const int32_t di = (int32_t)(lag * kk) - (int32_t)s1;
+            const uint32_t V = lag * s2 - s1 * s1;
+            const float Df = fabsf((float)di);
+            const float Rf = thr_abs * __builtin_amdgcn_sqrtf(cvar * (float)V);
+            const float diff = Df - Rf;
+            const float G = __builtin_fmaf(g1, (float)s1, __builtin_fmaf(g23, Df + Rf, g0));
+            decided = fabsf(diff) > G ? (decided | bit) : (decided & ~bit);
+            isconst = (V | (uint32_t)di) == 0u ? (isconst | bit) : (isconst & ~bit);
+            crest = (diff > 0.0f && di > 0) ? (crest | bit) : (crest & ~bit);
+            trough = (diff > 0.0f && di < 0) ? (trough | bit) : (trough & ~bit);
+        }
+        crest &= can & decided;
+        trough &= can & decided;
+        pend = can & ~decided;
+        // homopolymer / N runs: V == 0 and D == 0, settled by the precomputed table (rare)
+        uint32_t pc = pend & isconst;
+        pend &= ~pc;
+        if (__ballot(pc != 0u)) {
+            while (pc) {
+                const int q = __ffs((int)pc) - 1;
+                pc &= pc - 1u;
+                const uint32_t kk = K[base + (uint32_t)q + lag + 1u];
+                const int sg = a.const_sig[kk];
+                crest |= sg > 0 ? 1u << q : 0u;
+                trough |= sg < 0 ? 1u << q : 0u;
+            }
         }
     }
     wave_stamp(a, 4);
@@ -572,7 +621,8 @@ __global__ __launch_bounds__(256) void wave_fast_kernel(const WaveArgs a) {
             const int sg = exact_signal_wave(K, baseL + q + first, baseL + q + lag + 1u, lag, a.fsize, a.thr);
             if (lane == (uint32_t)L) {
                 pend &= ~(1u << q);
-                sigbits |= (uint64_t)(sg & 3) << (2u * q);
+                crest |= sg > 0 ? 1u << q : 0u;
+                trough |= sg < 0 ? 1u << q : 0u;
             }
             ++n_exact;
             bal = __ballot(pend != 0u);
@@ -586,10 +636,8 @@ __global__ __launch_bounds__(256) void wave_fast_kernel(const WaveArgs a) {
     if (want_dense) {
         if (base < nvalid) {
 #pragma unroll
-            for (int q = 0; q < W; ++q) {
-                const uint32_t code = (uint32_t)(sigbits >> (2 * q)) & 3u;
-                SG[base + q] = (uint8_t)(code == 3u ? 0xFFu : code);
-            }
+            for (int q = 0; q < W; ++q)
+                SG[base + q] = (uint8_t)(((crest >> q) & 1u) | (((trough >> q) & 1u) ? 0xFFu : 0u));
         }
         __syncthreads();
         for (uint32_t idx = tid; idx < nvalid; idx += 256u) {
@@ -600,8 +648,8 @@ __global__ __launch_bounds__(256) void wave_fast_kernel(const WaveArgs a) {
 
     // ---- phase 4b: ordered compaction: thread order == window order ----------
     if (want_peaks) {
-        // bit 0 of every 2-bit code is set for both crest (1) and trough (3)
-        const uint32_t mine = (uint32_t)__popcll(sigbits & 0x5555555555555555ull);
+        const uint32_t both = crest | trough;
+        const uint32_t mine = (uint32_t)__popc(both);
         uint32_t tot;
         const uint32_t ex = block_excl_scan_256<uint32_t>(mine, scr, tot);
         const uint32_t shard = blockIdx.x & (kShards - 1u);
@@ -616,11 +664,11 @@ __global__ __launch_bounds__(256) void wave_fast_kernel(const WaveArgs a) {
         if (mine) {
             gams_peak_t *const region = a.peaks + (size_t)shard * a.shard_cap;
             unsigned long long pos = reinterpret_cast<const unsigned long long *>(scr + 8)[0] + ex;
-            uint64_t bits = sigbits;
+            uint32_t bits = both;
             while (bits) {
-                const int q = (__ffsll((unsigned long long)bits) - 1) >> 1;
-                const uint32_t code = (uint32_t)(bits >> (2 * q)) & 3u;
-                bits &= ~(3ull << (2 * q));
+                const int q = __ffs((int)bits) - 1;
+                bits &= bits - 1u;
+                const uint32_t code = (crest >> q) & 1u;
                 if (pos < a.shard_cap) {
                     gams_peak_t pk;
                     pk.ctg = tl.ctg;
@@ -1239,9 +1287,10 @@ int gams_wave_plan_set_stamps(gams_gpu_t *h, gams_wave_plan_t *p, int enable) {
     (void)hipFree(p->d_stamps);
     p->d_stamps = nullptr;
     if (enable) {
-        const size_t n = std::max<size_t>(p->tiles.size(), 1) * 8;
+        const size_t n = std::max<size_t>(p->tiles.size(), 1) * 16;
         GAMS_HIP(h, hipMalloc(&p->d_stamps, n * sizeof(unsigned long long)));
-        GAMS_HIP(h, hipMemset(p->d_stamps, 0, n * sizeof(unsigned long long)));
+        GAMS_HIP(h, hipMemsetAsync(p->d_stamps, 0, n * sizeof(unsigned long long), h->compute));
+        GAMS_HIP(h, hipStreamSynchronize(h->compute));
     }
     return GAMS_OK;
 }
@@ -1252,27 +1301,41 @@ int gams_wave_stamps(gams_gpu_t *h, gams_wave_plan_t *p, double *mean_cycles, ui
     GAMS_HIP(h, hipSetDevice(h->device));
     GAMS_HIP(h, hipStreamSynchronize(h->compute));
     const size_t nt = p->tiles.size();
-    std::vector<unsigned long long> st(std::max<size_t>(nt, 1) * 8);
+    std::vector<unsigned long long> st(std::max<size_t>(nt, 1) * 16);
     GAMS_HIP(h, hipMemcpy(st.data(), p->d_stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (int k = 0; k < 8; ++k) mean_cycles[k] = 0.0;
-    unsigned long long lo = ~0ull, hi = 0;
     size_t used = 0;
+    unsigned long long r_lo = ~0ull, r_hi = 0, r_sum = 0;
+    double cyc_sum = 0.0;
     for (size_t t = 0; t < nt; ++t) {
-        bool ok = true;  // clocks of different XCDs are not comparable; drop anything odd
-        for (int k = 0; k < 6; ++k)
-            ok &= st[t * 8 + k] != 0 && st[t * 8 + k + 1] >= st[t * 8 + k] &&
-                  st[t * 8 + k + 1] - st[t * 8 + k] < (1ull << 28);
+        const unsigned long long *w = &st[t * 16];
+        bool ok = w[8] != 0 && w[9] >= w[8];
+        for (int k = 0; k < 6; ++k) ok &= w[k] != 0 && w[k + 1] >= w[k] && w[k + 1] - w[k] < (1ull << 28);
         if (!ok) continue;
         ++used;
-        for (int k = 0; k < 6; ++k) mean_cycles[k] += (double)(st[t * 8 + k + 1] - st[t * 8 + k]);
-        mean_cycles[6] += (double)(st[t * 8 + 6] - st[t * 8]);
-        lo = std::min(lo, st[t * 8]);
-        hi = std::max(hi, st[t * 8 + 6]);
+        for (int k = 0; k < 6; ++k) mean_cycles[k] += (double)(w[k + 1] - w[k]);
+        mean_cycles[6] += (double)(w[6] - w[0]);
+        r_lo = std::min(r_lo, w[8]);
+        r_hi = std::max(r_hi, w[9]);
+        r_sum += w[9] - w[8];
+        cyc_sum += (double)(w[6] - w[0]);
     }
     if (used)
         for (int k = 0; k < 7; ++k) mean_cycles[k] /= (double)used;
-    mean_cycles[7] = (double)used;
-    *span_cycles = used ? hi - lo : 0;
+    // shader clock in GHz = cycles / (ticks * 10 ns)
+    mean_cycles[7] = r_sum ? cyc_sum / ((double)r_sum * 10.0) : 0.0;
+    // high half: launch span in 10-ns ticks; low half: sum of workgroup lifetimes in ticks / 16
+    *span_cycles = used ? (((r_hi - r_lo) & 0xffffffffull) << 32) | ((r_sum >> 4) & 0xffffffffull) : 0;
+    return GAMS_OK;
+}
+
+int gams_wave_stamps_raw(gams_gpu_t *h, gams_wave_plan_t *p, uint64_t *out, uint64_t n_words) {
+    if (!h || !p || !out) return gams_fail(h, GAMS_EINVAL, "wave_stamps_raw: null argument");
+    if (!p->d_stamps) return gams_fail(h, GAMS_ESTATE, "wave_stamps_raw: stamps are off");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    GAMS_HIP(h, hipStreamSynchronize(h->compute));
+    const uint64_t n = std::min<uint64_t>(n_words, (uint64_t)p->tiles.size() * 16);
+    GAMS_HIP(h, hipMemcpy(out, p->d_stamps, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return GAMS_OK;
 }
 

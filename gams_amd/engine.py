@@ -147,7 +147,10 @@ class WavePlan:
         span = C.c_uint64()
         self.eng.check(self.eng.lib.gams_wave_stamps(self.eng.h, self.p, m, C.byref(span)))
         self.eng.check(self.eng.lib.gams_wave_plan_set_stamps(self.eng.h, self.p, 0))
-        return list(m)[:7], span.value
+        span_ticks, sum_ticks = span.value >> 32, (span.value & 0xffffffff) * 16
+        info = dict(clock_ghz=m[7], span_us=span_ticks / 100.0,
+                    mean_resident_wg=(sum_ticks / span_ticks) if span_ticks else 0.0)
+        return list(m)[:7], info
 
     def exact_count(self):
         n = C.c_uint64()

@@ -122,6 +122,8 @@ int gams_wave_exact_count(gams_gpu_t *h, gams_wave_plan_t *p, uint64_t *n_exact)
 int gams_wave_plan_set_stamps(gams_gpu_t *h, gams_wave_plan_t *p, int enable);
 int gams_wave_stamps(gams_gpu_t *h, gams_wave_plan_t *p, double *mean_cycles /* [8] */,
                      uint64_t *span_cycles);
+/* the raw stamp words: 16 per workgroup (tile), see wave_stamp() in gams_amd/csrc/wave.hip */
+int gams_wave_stamps_raw(gams_gpu_t *h, gams_wave_plan_t *p, uint64_t *out, uint64_t n_words);
 
 /* Convenience, one ctg from host memory (what wave.rs:143-155 computes):
  * gc_count / signal receive n = gams_window_count(len,size,step) items. */

@@ -24,7 +24,7 @@ def profile(eng, ctgs, label, tiles, step=10, reps=20):
         m, span = plan.stamps()
         nw = plan.total_windows
         print(f"{label} tile={tw or 'auto'} windows={nw} launch={ms * 1e3:.1f} us  {nw / ms / 1e6:.1f} Gwin/s "
-              f"{nw * step / ms / 1e6:.0f} GB/s  span={span} cyc")
+              f"{nw * step / ms / 1e6:.0f} GB/s  {span}")
         print("   " + "  ".join(f"{n}={v:.0f}" for n, v in zip(NAMES, m)))
         plan.close()
     ss.close()

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Dump per-workgroup timing of one S288c-sized launch: when each workgroup entered, how long it
+lived, which XCD / CU ran it."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gams_amd import _lib, engine, synth  # noqa: E402
+
+eng = engine.Engine(0)
+ctgs = synth.genome_ctgs(synth.S288C_LENGTHS, 500000)
+ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])
+tw = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+plan = engine.WavePlan(eng, ss, 100, 10, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS, tile_windows=tw)
+for _ in range(5):
+    plan.run()
+eng.sync()
+eng.check(eng.lib.gams_wave_plan_set_stamps(eng.h, plan.p, 1))
+plan.run()
+eng.sync()
+nt = 20000
+buf = np.zeros(nt * 16, np.uint64)
+eng.check(eng.lib.gams_wave_stamps_raw(eng.h, plan.p, buf.ctypes.data, buf.size))
+st = buf.reshape(-1, 16)
+st = st[st[:, 10] != 0]
+t0 = st[:, 10].min()
+entry = (st[:, 10] - t0) / 100.0
+s0 = (st[:, 8] - t0) / 100.0
+end = (st[:, 9] - t0) / 100.0
+xcc = (st[:, 11] >> np.uint64(32)).astype(int)
+hw = (st[:, 11] & np.uint64(0xffffffff)).astype(int)
+cu = (hw >> 8) & 0xf
+sh = (hw >> 12) & 1
+se = (hw >> 13) & 0x7
+print("workgroups", len(st), "span us", end.max())
+print("entry percentiles us", np.percentile(entry, [0, 10, 50, 90, 99, 100]).round(2))
+print("entry->stamp0 us", np.percentile(s0 - entry, [0, 50, 90, 100]).round(2))
+print("stamp0->end us", np.percentile(end - s0, [0, 50, 90, 100]).round(2))
+print("per-xcc count", np.bincount(xcc, minlength=8))
+key = xcc * 1000 + se * 100 + sh * 16 + cu
+uk, cnt = np.unique(key, return_counts=True)
+print("distinct CUs used", len(uk), "wg per CU min/median/max", cnt.min(), np.median(cnt), cnt.max())
+order = np.argsort(entry)
+print("first 12 entries", entry[order][:12].round(2), "\nlast 12", entry[order][-12:].round(2))
+# time line: number of resident workgroups every microsecond
+for t in np.arange(0, end.max(), 1.0):
+    print(f"t={t:5.1f} resident={int(((entry <= t) & (end > t)).sum())}")
