@@ -27,6 +27,7 @@ WORKLOADS = {
     # name: (chromosome lengths, piece, size, step, lag)
     "S288c": ("S288C_LENGTHS", 500000, 100, 10, 100),
     "Atha": ("ATHA_LENGTHS", 500000, 100, 10, 100),
+    "synth384": ("SYNTH384_LENGTHS", 1000000, 100, 10, 100),
     "GRCh38-step10": ("GRCH38_LENGTHS", 1000000, 100, 10, 100),
     "GRCh38-step1": ("GRCH38_LENGTHS", 1000000, 100, 1, 100),
 }
@@ -161,7 +162,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "wave_tile_kernel",
+                "kernel": "wave_fast_kernel",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
@@ -194,7 +195,7 @@ def main():
         ss.close()
         from gams_amd import synth
 
-        big = synth.genome_ctgs([16_000_000] * 24, 1000000, first_chr_index=500)
+        big = synth.genome_ctgs(synth.SYNTH384_LENGTHS, 1000000, first_chr_index=500)
         ss = engine.SeqSet(eng, [c["seq"] for c in big])
         plan = engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS, tile_windows=args.tile, **prm)
         for _ in range(3):

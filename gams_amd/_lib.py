@@ -74,6 +74,16 @@ PROTOTYPES = {
 _lib = None
 
 
+def bind(path):
+    """dlopen one build of the library and bind every prototype of include/gams_gpu.h."""
+    lib = C.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
 def load():
     """dlopen libgams_gpu.so and bind every prototype; raises if anything is missing."""
     global _lib
@@ -83,10 +93,5 @@ def load():
         raise ImportError(
             f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-    lib = C.CDLL(SO_PATH)
-    for name, (res, args) in PROTOTYPES.items():
-        fn = getattr(lib, name)  # AttributeError if the .so does not export it
-        fn.restype = res
-        fn.argtypes = args
-    _lib = lib
-    return lib
+    _lib = bind(SO_PATH)
+    return _lib

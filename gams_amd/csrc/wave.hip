@@ -409,8 +409,10 @@ __global__ void wave_const_table_kernel(int8_t *const_sig, uint32_t size, uint32
 //            rolled sums.
 //   phase 4  per-thread peak counts -> one workgroup scan -> one atomic per tile.
 // =============================================================================
+// __launch_bounds__(256, 8): 8 waves per SIMD = 8 workgroups per CU, i.e. at most 64 VGPRs.
+// Interleaved A/B (tools/ab.py) on 384 Mb: W = 12 runs 115 -> 105 us with the cap.
 template <int W>
-__global__ __launch_bounds__(256) void wave_fast_kernel(const WaveArgs a) {
+__global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
     static_assert(W % 4 == 0 && ((W / 4) & 1) == 1, "W/4 must be odd (LDS bank stride)");
     if (a.stamps != nullptr && threadIdx.x == 0)
         a.stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();  // workgroup entry
@@ -915,10 +917,11 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
                 if (tw_req == tw) pick = w;
                 continue;
             }
-            // enough tiles to fill 256 CUs several times over, else smaller tiles
+            // default: W = 12 once that still gives >= 4 tiles per CU, else W = 4 (more, shorter
+            // workgroups: a small genome is launch-latency bound).  W = 20 only on request.
             const uint64_t tiles = p->total_windows / tw;
-            if (pick == 0 && (tiles >= 2048 || w == 4)) pick = w;
             if (pick == 0 && w == 12 && tiles >= 1024) pick = w;
+            if (pick == 0 && w == 4) pick = w;
         }
         if (pick) {
             p->fast_w = pick;

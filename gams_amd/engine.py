@@ -19,8 +19,8 @@ def _u8(buf):
 class Engine:
     """One handle = one device + its streams (gams_gpu_create)."""
 
-    def __init__(self, device=0):
-        self.lib = _lib.load()
+    def __init__(self, device=0, lib=None):
+        self.lib = lib if lib is not None else _lib.load()   # `lib`: an alternative build (tools/ab.py)
         h = C.c_void_p()
         rc = self.lib.gams_gpu_create(device, C.byref(h))
         if rc != _lib.OK:

@@ -22,6 +22,8 @@ GRCH38_LENGTHS = [248956422, 242193529, 198295559, 190214555, 181538259, 1708059
                   138394717, 133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345,
                   83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415]
 
+SYNTH384_LENGTHS = [16_000_000] * 24   # 384 Mb: larger than the 256 MiB Infinity Cache
+
 _CHUNK = 1 << 24
 
 
