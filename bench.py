@@ -23,6 +23,20 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
+
+def profiled_traffic(workload):
+    """HBM bytes per launch of the wave kernel from the committed rocprofv3 PMC passes
+    (profiles/*_pmc.json, made by tools/prof.sh): FETCH_SIZE and WRITE_SIZE are in KiB and were
+    collected in separate passes; on gfx950 FETCH_SIZE counts half the bytes of a wide coalesced
+    stream, so it is doubled (MI355X_MICROARCH.md, HBM section).  None if no profile matches."""
+    path = os.path.join(ROOT, "profiles", f"r01_{workload}_wave_pmc.json")
+    try:
+        with open(path) as fh:
+            p = json.load(fh)
+        return (2.0 * p["FETCH_SIZE"]["mean"] + p["WRITE_SIZE"]["mean"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
+
 WORKLOADS = {
     # name: (chromosome lengths, piece, size, step, lag)
     "S288c": ("S288C_LENGTHS", 500000, 100, 10, 100),
@@ -86,15 +100,21 @@ def main():
     import torch
 
     dist = None
+    n_dev = torch.cuda.device_count()
+    device = local_rank % max(n_dev, 1)
+    backend = os.environ.get("GAMS_BENCH_BACKEND", "nccl")   # "gloo": rehearsal with several ranks on one GPU
     if world > 1:
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
 
     from gams_amd import _lib, engine
 
-    eng = engine.Engine(local_rank)
+    eng = engine.Engine(device)
     arch, cus, hbm = eng.device_info()
 
     ctgs, prm, genome_bp = build_workload(args.workload, rank, args.scale)
@@ -120,10 +140,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        red_dev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        w = torch.tensor([float(n_windows)], dtype=torch.float64, device="cuda")
+        w = torch.tensor([float(n_windows)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(w, op=dist.ReduceOp.SUM)
         total_windows = float(w.item())
     else:
@@ -167,7 +188,8 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": profiled_traffic(args.workload) if args.scale == 1.0 and args.tile == 0 else None,
+                "algorithmic_bytes": int(n_windows) * step_bytes,
                 "bytes_per_window": step_bytes,
                 "launch_ms": launch_ms,
             },

@@ -419,9 +419,10 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
     constexpr uint32_t TW = 256u * W;
     constexpr int WD = W / 4;
     extern __shared__ __align__(16) unsigned char smem[];
-    // LDS carve: PM | scratch (16 words) | K | SG (dense only)
-    uint32_t *PM = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *scr = PM + ((a.max_chunks + 4u) & ~3u);
+    // LDS carve: BM (1 bit per base, 16 per chunk) | scratch (16 words) | K | SG (dense only)
+    uint16_t *BM = reinterpret_cast<uint16_t *>(smem);
+    const uint32_t *BW = reinterpret_cast<const uint32_t *>(smem);
+    uint32_t *scr = reinterpret_cast<uint32_t *>(smem) + (((a.max_chunks + 8u) >> 1) + 3u & ~3u);
     uint8_t *K = reinterpret_cast<uint8_t *>(scr + 16);
     const uint32_t *KW = reinterpret_cast<const uint32_t *>(K);
     uint8_t *SG = K + ((TW + a.lag + 1u + 31u) & ~15u);
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
     // ---- phase 1: load + classify ------------------------------------------
     // Two batches of four 16-B loads stay in flight per thread: the next batch is issued
     // before the current one is classified.  Loads and LDS stores are unconditional (index
-    // clamped to the last chunk / parked on the sentinel slot, which phase 1b rewrites):
+    // clamped to the last chunk / parked on the slot behind the last chunk, never read):
     // a predicated load sits in its own basic block and makes hipcc wait vmcnt(0).
     {
         const uint32_t last = nchunk - 1u;
@@ -456,43 +457,76 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) nxt[k] = src[min(c0 + 1024u + 256u * k, last)];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) PM[min(c0 + 256u * k, nchunk)] = gc_mask16(cur[k]);
+            for (int k = 0; k < 4; ++k) BM[min(c0 + 256u * k, nchunk)] = (uint16_t)gc_mask16(cur[k]);
 #pragma unroll
             for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
         }
     }
     __syncthreads();
     wave_stamp(a, 1);
-
-    // ---- phase 1b: exclusive prefix of chunk popcounts ----------------------
-    {
-        const uint32_t cpt = ((nchunk + 255u) >> 8) | 1u;
-        const uint32_t cb = min(tid * cpt, nchunk), ce = min(cb + cpt, nchunk);
-        uint32_t s = 0;
-        for (uint32_t c = cb; c < ce; ++c) s += __popc(PM[c]);
-        uint32_t tot;
-        uint32_t run = block_excl_scan_256<uint32_t>(s, scr, tot);
-        for (uint32_t c = cb; c < ce; ++c) {
-            const uint32_t m = PM[c];
-            PM[c] = (run << 16) | m;
-            run += __popc(m);
-        }
-        if (cb < ce && ce == nchunk) PM[nchunk] = run << 16;
-    }
-    __syncthreads();
     wave_stamp(a, 2);
 
-    // ---- phase 2: k of every slot (interleaved: neighbouring lanes, neighbouring bytes)
+    // ---- phase 2: k of every slot, rolling over the bit stream ------------------
+    // Thread t owns a run of consecutive slots.  Its first window is counted directly
+    // (popcount of `size` bits); every further window adds the popcount of the `step`
+    // bits entering on the right and subtracts the `step` bits leaving on the left:
+    // two 64-bit LDS reads, two shifts, two masks, two popcounts per window, for any
+    // size and any step <= 32.  No byte prefix is ever built.
     {
         const uint32_t nK = lag + 1u + nvalid;
-        for (uint32_t idx = tid; idx < nK; idx += 256u) {
-            const int32_t v = vb + (int32_t)idx;
-            uint32_t kk = 0;
-            if (v >= 0) {
-                const uint32_t x = (uint32_t)v * step - a0;
-                kk = gc_prefix_at(PM, x + size) - gc_prefix_at(PM, x);
+        const uint32_t run = (nK + 255u) >> 8;
+        uint32_t idx = tid * run;
+        const uint32_t iend = min(idx + run, nK);
+        for (; idx < iend && vb + (int32_t)idx < 0; ++idx) K[idx] = 0;   // before the ctg start
+        if (idx < iend) {
+            uint32_t x = (uint32_t)(vb + (int32_t)idx) * step - a0;      // bit = base position
+            // direct count of bits [x, x + size)
+            uint32_t k = 0;
+            {
+                const uint32_t e = x + size;
+                for (uint32_t d = x >> 5; d <= (e - 1u) >> 5; ++d) {
+                    uint32_t w = BW[d];
+                    const uint32_t lo = d << 5;
+                    if (lo < x) w &= ~0u << (x - lo);
+                    if (lo + 32u > e) w &= ~0u >> (lo + 32u - e);
+                    k += __popc(w);
+                }
             }
-            K[idx] = (uint8_t)kk;
+            K[idx++] = (uint8_t)k;
+            const uint32_t fmask = step >= 32u ? ~0u : (1u << step) - 1u;
+            // four windows per trip: all eight 64-bit LDS reads are issued before any store
+            // (K and the bit stream share the LDS array, so the compiler will not reorder them)
+            for (; idx + 4u <= iend; idx += 4u, x += 4u * step) {
+                uint32_t nl[4], nh[4], ol[4], oh[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t po = x + (uint32_t)j * step, pn = po + size;
+                    nl[j] = BW[pn >> 5];
+                    nh[j] = BW[(pn >> 5) + 1u];
+                    ol[j] = BW[po >> 5];
+                    oh[j] = BW[(po >> 5) + 1u];
+                }
+                uint32_t kq[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t po = x + (uint32_t)j * step, pn = po + size;
+                    const uint64_t wn = ((uint64_t)nh[j] << 32) | nl[j];
+                    const uint64_t wo = ((uint64_t)oh[j] << 32) | ol[j];
+                    k += __popc((uint32_t)(wn >> (pn & 31u)) & fmask);
+                    k -= __popc((uint32_t)(wo >> (po & 31u)) & fmask);
+                    kq[j] = k;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) K[idx + j] = (uint8_t)kq[j];
+            }
+            for (; idx < iend; ++idx, x += step) {
+                const uint32_t pn = x + size, po = x;
+                const uint64_t wn = ((uint64_t)BW[(pn >> 5) + 1u] << 32) | BW[pn >> 5];
+                const uint64_t wo = ((uint64_t)BW[(po >> 5) + 1u] << 32) | BW[po >> 5];
+                k += __popc((uint32_t)(wn >> (pn & 31u)) & fmask);
+                k -= __popc((uint32_t)(wo >> (po & 31u)) & fmask);
+                K[idx] = (uint8_t)k;
+            }
         }
     }
     __syncthreads();
@@ -883,7 +917,7 @@ void wave_guard_band(const gams_wave_params_t &p, float g[4]) {
 }
 
 size_t wave_fast_lds_bytes(uint32_t max_chunks, uint32_t tw, uint32_t lag, bool dense) {
-    size_t b = (size_t)((max_chunks + 4u) & ~3u) * 4;   // PM
+    size_t b = (size_t)((((max_chunks + 8u) >> 1) + 3u) & ~3u) * 4;   // BM: 16 mask bits per chunk
     b += 16 * 4;                                         // scratch
     b += (tw + lag + 1u + 31u) & ~15u;                   // K
     if (dense) b += (tw + 15u) & ~15u;                   // SG
@@ -905,7 +939,7 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
     p->fast_w = 0;
     p->attr_set = false;
     // fast kernel: 8-bit counts, 32-bit variance math with 24-bit multiplies
-    const bool fast_ok = !p->serial && q.size <= 255 && (uint64_t)q.lag * q.size <= 65535 &&
+    const bool fast_ok = !p->serial && q.size <= 255 && q.step <= 32 && (uint64_t)q.lag * q.size <= 65535 &&
                          (uint64_t)q.lag * q.size * q.size < (1ull << 24) && q.lag >= 2;
     if (fast_ok && (tw_req == 0 || tw_req == 1024 || tw_req == 3072 || tw_req == 5120)) {
         static const int cand[3] = {20, 12, 4};
