@@ -411,9 +411,12 @@ __global__ void wave_const_table_kernel(int8_t *const_sig, uint32_t size, uint32
 // =============================================================================
 // __launch_bounds__(256, 8): 8 waves per SIMD = 8 workgroups per CU, i.e. at most 64 VGPRs.
 // Interleaved A/B (tools/ab.py) on 384 Mb: W = 12 runs 115 -> 105 us with the cap.
-template <int W>
+// SIZE/STEP/LAG != 0 bake the headline parameters into the instruction stream (constant
+// bit-field offsets in phase 2); 0 = taken from the arguments at run time.
+template <int W, int SIZE, int STEP, int LAG>
 __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
     static_assert(W % 4 == 0 && ((W / 4) & 1) == 1, "W/4 must be odd (LDS bank stride)");
+    static_assert((SIZE == 0) == (STEP == 0) && (SIZE == 0) == (LAG == 0), "bake all three or none");
     if (a.stamps != nullptr && threadIdx.x == 0)
         a.stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();  // workgroup entry
     constexpr uint32_t TW = 256u * W;
@@ -422,15 +425,16 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
     // LDS carve: BM (1 bit per base, 16 per chunk) | scratch (16 words) | K | SG (dense only)
     uint16_t *BM = reinterpret_cast<uint16_t *>(smem);
     const uint32_t *BW = reinterpret_cast<const uint32_t *>(smem);
-    uint32_t *scr = reinterpret_cast<uint32_t *>(smem) + (((a.max_chunks + 8u) >> 1) + 3u & ~3u);
+    uint32_t *scr = reinterpret_cast<uint32_t *>(smem) + ((((a.max_chunks + 8u) >> 1) + 16u + 3u) & ~3u);
     uint8_t *K = reinterpret_cast<uint8_t *>(scr + 16);
     const uint32_t *KW = reinterpret_cast<const uint32_t *>(K);
-    uint8_t *SG = K + ((TW + a.lag + 1u + 31u) & ~15u);
+    uint8_t *SG = K + ((TW + (LAG ? (uint32_t)LAG : a.lag) + 1u + 31u) & ~15u);
 
     const uint32_t tid = threadIdx.x;
     const WaveTile tl = a.tiles[blockIdx.x];
     const struct { uint64_t seq_off, win_base; uint32_t n_win; } cg = {tl.seq_off, tl.win_base, tl.n_win};
-    const uint32_t lag = a.lag, step = a.step, size = a.size;
+    const uint32_t lag = LAG ? (uint32_t)LAG : a.lag, step = STEP ? (uint32_t)STEP : a.step,
+                   size = SIZE ? (uint32_t)SIZE : a.size;
     const uint32_t w0 = tl.w0;
     const uint32_t w1 = min(w0 + TW, cg.n_win);
     const uint32_t nvalid = w1 - w0;
@@ -472,7 +476,54 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
     // bits entering on the right and subtracts the `step` bits leaving on the left:
     // two 64-bit LDS reads, two shifts, two masks, two popcounts per window, for any
     // size and any step <= 32.  No byte prefix is ever built.
-    {
+    bool counted = false;
+    if constexpr (STEP != 0) {
+        // Baked parameters, tiles behind the ctg start (vb >= 0): a thread takes RUN
+        // consecutive slots, pulls the RUN*STEP + SIZE bits they span into registers once,
+        // realigns them to bit 0 (v_alignbit), and every field is then a v_bfe at a constant
+        // offset: ~6 VALU per window, no LDS access inside the run, counts stored 4 per dword.
+        if (vb >= 0) {
+            counted = true;
+            constexpr uint32_t NK_MAX = (uint32_t)LAG + 1u + TW;
+            constexpr uint32_t RUN = (((NK_MAX + 255u) / 256u) + 3u) & ~3u;
+            constexpr uint32_t NBITS = RUN * (uint32_t)STEP + (uint32_t)SIZE;
+            constexpr uint32_t NDW = (NBITS + 31u) / 32u + 1u;           // + 1 for the realignment
+            const uint32_t nK = lag + 1u + nvalid;
+            const uint32_t idx0 = tid * RUN;
+            if (idx0 < nK) {
+                const uint32_t x0 = ((uint32_t)vb + idx0) * (uint32_t)STEP - a0;
+                const uint32_t d0 = x0 >> 5, sh = x0 & 31u;
+                uint32_t r[NDW];
+#pragma unroll
+                for (uint32_t i = 0; i < NDW; ++i) r[i] = BW[d0 + i];
+#pragma unroll
+                for (uint32_t i = 0; i + 1u < NDW; ++i) r[i] = __builtin_amdgcn_alignbit(r[i + 1u], r[i], sh);
+                auto field = [&](uint32_t off) -> uint32_t {           // STEP bits at constant bit `off`
+                    const uint32_t d = off >> 5, s = off & 31u;
+                    if (s + (uint32_t)STEP <= 32u) return __builtin_amdgcn_ubfe(r[d], s, (uint32_t)STEP);
+                    return __builtin_amdgcn_alignbit(r[d + 1u], r[d], s) & ((1u << STEP) - 1u);
+                };
+                uint32_t k = 0;
+#pragma unroll
+                for (uint32_t d = 0; d < (uint32_t)SIZE / 32u; ++d) k += __popc(r[d]);
+                if constexpr (SIZE % 32 != 0) k += __popc(r[SIZE / 32] & ((1u << (SIZE % 32)) - 1u));
+                uint32_t packed = k;
+#pragma unroll
+                for (uint32_t j = 1; j < RUN; ++j) {
+                    k += __popc(field((uint32_t)SIZE + (j - 1u) * (uint32_t)STEP));
+                    k -= __popc(field((j - 1u) * (uint32_t)STEP));
+                    if ((j & 3u) == 0u) {
+                        if (idx0 + j - 4u < nK) reinterpret_cast<uint32_t *>(K)[(idx0 + j - 4u) >> 2] = packed;
+                        packed = k;
+                    } else {
+                        packed |= k << (8u * (j & 3u));
+                    }
+                }
+                if (idx0 + RUN - 4u < nK) reinterpret_cast<uint32_t *>(K)[(idx0 + RUN - 4u) >> 2] = packed;
+            }
+        }
+    }
+    if (!counted) {
         const uint32_t nK = lag + 1u + nvalid;
         const uint32_t run = (nK + 255u) >> 8;
         uint32_t idx = tid * run;
@@ -917,7 +968,7 @@ void wave_guard_band(const gams_wave_params_t &p, float g[4]) {
 }
 
 size_t wave_fast_lds_bytes(uint32_t max_chunks, uint32_t tw, uint32_t lag, bool dense) {
-    size_t b = (size_t)((((max_chunks + 8u) >> 1) + 3u) & ~3u) * 4;   // BM: 16 mask bits per chunk
+    size_t b = (size_t)((((max_chunks + 8u) >> 1) + 16u + 3u) & ~3u) * 4;   // BM: 16 mask bits per chunk + pad
     b += 16 * 4;                                         // scratch
     b += (tw + lag + 1u + 31u) & ~15u;                   // K
     if (dense) b += (tw + 15u) & ~15u;                   // SG
@@ -1027,9 +1078,9 @@ int wave_launch(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a) {
     return GAMS_OK;
 }
 
-template <int W>
+template <int W, int SIZE, int STEP, int LAG>
 int wave_launch_fast(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a) {
-    auto kern = wave_fast_kernel<W>;
+    auto kern = wave_fast_kernel<W, SIZE, STEP, LAG>;
     if (!p->attr_set) {
         GAMS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
@@ -1210,12 +1261,13 @@ int gams_wave_run(gams_gpu_t *h, gams_wave_plan_t *p) {
     a.dense_cnt = p->d_dense_cnt;
     a.dense_sig = p->d_dense_sig;
     int rc;
+    const bool headline = q.size == 100 && q.step == 10 && q.lag == 100;   // every BASELINE step-10 config
     if (p->fast_w == 20)
-        rc = wave_launch_fast<20>(h, p, a);
+        rc = wave_launch_fast<20, 0, 0, 0>(h, p, a);
     else if (p->fast_w == 12)
-        rc = wave_launch_fast<12>(h, p, a);
+        rc = headline ? wave_launch_fast<12, 100, 10, 100>(h, p, a) : wave_launch_fast<12, 0, 0, 0>(h, p, a);
     else if (p->fast_w == 4)
-        rc = wave_launch_fast<4>(h, p, a);
+        rc = headline ? wave_launch_fast<4, 100, 10, 100>(h, p, a) : wave_launch_fast<4, 0, 0, 0>(h, p, a);
     else if (p->k16)
         rc = p->wide ? wave_launch<uint16_t, true>(h, p, a) : wave_launch<uint16_t, false>(h, p, a);
     else
