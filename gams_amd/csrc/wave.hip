@@ -391,6 +391,18 @@ __global__ void wave_const_table_kernel(int8_t *const_sig, uint32_t size, uint32
     const_sig[k] = (int8_t)sg;
 }
 
+// acc = 2*acc + (x > y): the comparison lands in VCC and v_addc_co shifts it into the
+// accumulator, 2 VALU per recorded bit (a cndmask/or chain costs 3).  Bits arrive MSB first.
+__device__ __forceinline__ void push_gt_f32(uint32_t &acc, float x, float y) {
+    asm("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(x), "v"(y) : "vcc");
+}
+__device__ __forceinline__ void push_neg_gt_f32(uint32_t &acc, float x, float y) {   // (-x > y), negation free
+    asm("v_cmp_gt_f32_e64 vcc, -%1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(x), "v"(y) : "vcc");
+}
+__device__ __forceinline__ void push_gt_i32(uint32_t &acc, int32_t x, int32_t y) {
+    asm("v_cmp_gt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(x), "v"(y) : "vcc");
+}
+
 // =============================================================================
 // wave_fast_kernel<W>: the same tile algorithm specialised for 8-bit counts
 // (size <= 255) and 32-bit variance math (lag*size <= 65535, lag*size^2 < 2^24),
@@ -632,7 +644,8 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
             const uint32_t lo_q = w0 + base >= lag ? 0u : min((uint32_t)W, lag - (w0 + base));  // q >= lo_q
             can = ((1u << hi_q) - 1u) & ~((1u << lo_q) - 1u);
         }
-        uint32_t decided = 0, isconst = 0;
+        // per window three bits: sig (D - R > G), nos (R - D > G), up (n*k > S1)
+        uint32_t sigm = 0, nosm = 0, upm = 0;
 #pragma unroll
         for (int q = 0; q < W; ++q) {
             const uint32_t kout = (og[q >> 2] >> (8 * (q & 3))) & 0xFFu;
@@ -644,14 +657,19 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
             const float Rf = thr_abs * __builtin_amdgcn_sqrtf(cvar * (float)V);
             const float diff = Df - Rf;
             const float G = __builtin_fmaf(g1, (float)S1, __builtin_fmaf(g23, Df + Rf, g0));
-            const uint32_t bit = 1u << q;
-            decided |= fabsf(diff) > G ? bit : 0u;
-            isconst |= (V | (uint32_t)di) == 0u ? bit : 0u;                  // all lag counts equal kk
-            crest |= (diff > 0.0f && di > 0) ? bit : 0u;
-            trough |= (diff > 0.0f && di < 0) ? bit : 0u;
+            push_gt_f32(sigm, diff, G);
+            push_neg_gt_f32(nosm, diff, G);
+            push_gt_i32(upm, di, 0);
             S1 += kin - kout;
             S2 += __umul24(kin, kin) - __umul24(kout, kout);
         }
+        // window q sits at bit W-1-q of the accumulators: flip to bit q
+        sigm = __brev(sigm) >> (32 - W);
+        nosm = __brev(nosm) >> (32 - W);
+        upm = __brev(upm) >> (32 - W);
+        uint32_t decided = sigm | nosm;
+        crest = sigm & upm;
+        trough = sigm & ~upm;                    // D > R + G > 0, so di != 0 here
         // Window i == lag averages windows [0,lag) (stat.rs:30-31) like i == lag+1, not
         // [i-1-lag, i-1): its owner (one thread per ctg) redoes the integer decision with the
         // sums over K[base+qlag+1, base+qlag+1+lag).
@@ -672,24 +690,31 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
             const float diff = Df - Rf;
             const float G = __builtin_fmaf(g1, (float)s1, __builtin_fmaf(g23, Df + Rf, g0));
             decided = fabsf(diff) > G ? (decided | bit) : (decided & ~bit);
-            isconst = (V | (uint32_t)di) == 0u ? (isconst | bit) : (isconst & ~bit);
             crest = (diff > 0.0f && di > 0) ? (crest | bit) : (crest & ~bit);
             trough = (diff > 0.0f && di < 0) ? (trough | bit) : (trough & ~bit);
         }
         crest &= can & decided;
         trough &= can & decided;
         pend = can & ~decided;
-        // homopolymer / N runs: V == 0 and D == 0, settled by the precomputed table (rare)
-        uint32_t pc = pend & isconst;
-        pend &= ~pc;
-        if (__ballot(pc != 0u)) {
-            while (pc) {
-                const int q = __ffs((int)pc) - 1;
-                pc &= pc - 1u;
+        // homopolymer / N runs: all lag averaged counts and the window's own count equal
+        // (V == 0 and D == 0, undecidable in integers): settled by the precomputed table.
+        // Tested on demand for pending windows only (rare), straight from K.
+        if (__ballot(pend != 0u)) {
+            uint32_t todo = pend;
+            while (todo) {
+                const int q = __ffs((int)todo) - 1;
+                todo &= todo - 1u;
+                const uint32_t i = w0 + base + (uint32_t)q;
+                const uint32_t tj = base + (uint32_t)q + (i == lag ? 1u : 0u);
                 const uint32_t kk = K[base + (uint32_t)q + lag + 1u];
-                const int sg = a.const_sig[kk];
-                crest |= sg > 0 ? 1u << q : 0u;
-                trough |= sg < 0 ? 1u << q : 0u;
+                bool same = true;
+                for (uint32_t j = 0; j < lag && same; ++j) same = K[tj + j] == kk;
+                if (same) {
+                    const int sg = a.const_sig[kk];
+                    pend &= ~(1u << q);
+                    crest |= sg > 0 ? 1u << q : 0u;
+                    trough |= sg < 0 ? 1u << q : 0u;
+                }
             }
         }
     }
