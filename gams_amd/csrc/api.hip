@@ -100,7 +100,7 @@ int gams_seqset_create(gams_gpu_t *h, uint32_t n_ctg, const uint32_t *lengths, g
         s->off[i] = o;
         o += ((uint64_t)lengths[i] + 255u) & ~(uint64_t)255u;  // next ctg on a 256-B boundary
     }
-    s->bytes = o + 256;  // tail slack: kernels read whole 16-B chunks
+    s->bytes = o + 65536;  // tail slack: kernels read whole 16-B chunks, the baked wave kernels whole 4-KiB rows
     hipError_t e = hipMalloc(&s->d_seq, s->bytes);
     if (e != hipSuccess) {
         delete s;

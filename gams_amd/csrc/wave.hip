@@ -339,12 +339,20 @@ __device__ __forceinline__ float readlane_f32(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-// 64 sequential adds fed from the 64 lanes of `x` (constant lane numbers: no loop, no
-// scalar-register hazards beyond the readlane itself)
-__device__ __forceinline__ float seq_add_64(float acc, float x) {
+// Sequential f32 sum of the 64 lane values of `x` on top of `carry`, in lane order, as a
+// wavefront recurrence: s <- x + wave_shr:1(s), 63 times, lane 0 fed with the carry.  After
+// t steps lanes 0..t hold carry + x_0 + ... + x_l accumulated strictly left to right (f32
+// addition is commutative, so x_l + prefix_{l-1} is the reference's prefix_{l-1} + x_l), and
+// finished lanes no longer change.  One DPP add per element, no scalar round trip.
+__device__ __forceinline__ float seq_add_64(float carry, float x) {
+    float s = x + carry;   // only lane 0 keeps this; the others are overwritten below
 #pragma unroll
-    for (int l = 0; l < 64; ++l) acc = acc + readlane_f32(x, l);
-    return acc;
+    for (int t = 0; t < 63; ++t) {
+        const float prev = __int_as_float(
+            __builtin_amdgcn_update_dpp(__float_as_int(carry), __float_as_int(s), 0x138, 0xf, 0xf, false));
+        s = x + prev;       // lane 0: x_0 + carry again (bound lanes take `old` = carry)
+    }
+    return readlane_f32(s, 63);
 }
 
 __device__ __noinline__ int exact_signal_wave(const uint8_t *K, uint32_t tj, uint32_t ti, uint32_t n,
@@ -460,6 +468,18 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
 
     wave_stamp(a, 0);
     // ---- phase 1: load + classify ------------------------------------------
+    if constexpr (STEP != 0) {
+        // Baked parameters: the tile never has more than NCH chunks, so every thread issues
+        // all of its NLD loads back to back with no bounds logic (the bytes past the tile
+        // are the next tile's or the seqset's tail slack), classifies, and stores.
+        constexpr uint32_t NCH = ((uint32_t)TW * STEP + ((uint32_t)LAG + 1u) * STEP + SIZE + 30u) / 16u + 1u;
+        constexpr uint32_t NLD = (NCH + 255u) / 256u;
+        uint4 v[NLD];
+#pragma unroll
+        for (uint32_t k = 0; k < NLD; ++k) v[k] = src[tid + 256u * k];
+#pragma unroll
+        for (uint32_t k = 0; k < NLD; ++k) BM[tid + 256u * k] = (uint16_t)gc_mask16(v[k]);
+    } else
     // Two batches of four 16-B loads stay in flight per thread: the next batch is issued
     // before the current one is classified.  Loads and LDS stores are unconditional (index
     // clamped to the last chunk / parked on the slot behind the last chunk, never read):
@@ -1037,7 +1057,8 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
             p->fast_w = pick;
             p->tw = 256u * pick;
             p->max_win = p->tw + q.lag + 1;
-            p->max_chunks = (uint32_t)((halo_bytes + (uint64_t)p->tw * q.step + 15) / 16) + 1;
+            // rounded up to whole 256-chunk rows: the baked kernels store every row they load
+            p->max_chunks = ((uint32_t)((halo_bytes + (uint64_t)p->tw * q.step + 15) / 16) + 1 + 255u) & ~255u;
             p->k16 = false;
             p->wide = false;
             p->lds_bytes = wave_fast_lds_bytes(p->max_chunks, p->tw, q.lag, (p->flags & GAMS_WAVE_DENSE) != 0);
