@@ -52,8 +52,11 @@ struct WaveTile {
     uint64_t win_base;
 };
 
-// Peak records are appended through kShards independent counters (workgroup b uses shard
-// b % kShards, region shard*shard_cap of the record buffer): one contended counter word
+// Peak records: every tile owns a fixed slot of `tile_cap` records (tile t writes
+// peaks[t*tile_cap ...] and its count to tile_cnt[t]): no atomic, no ordering between
+// workgroups; gams_wave_peaks() packs the slots on the device.  (A single appended-to
+// counter serialises at ~88 atomics/us; 128 sharded counters still put a returning atomic
+// on every workgroup's critical path.)  The diagnostics counters stay sharded: one word
 // serialises at ~88 atomics/us, which a 1000-tile launch would feel.
 constexpr uint32_t kShards = 128;
 constexpr uint32_t kShardWords = 16;
@@ -71,10 +74,8 @@ struct WaveArgs {
     float g0, g1, g2, g3;  // guard band  G = g0 + g1*S1 + g2*R + g3*D
     // outputs
     gams_peak_t *peaks;
-    uint64_t shard_cap;            // records per shard region of `peaks`
-    unsigned long long *counters;  // kShards x 16 words (one 128-B line per shard): [0] peaks appended
-                                   // to the shard's region, [1] exact-path evaluations
-    unsigned long long *tile_off;
+    uint32_t tile_cap;             // records per tile slot of `peaks`
+    unsigned long long *counters;  // kShards x 16 words (one 128-B line per shard): [1] exact-path evaluations
     uint32_t *tile_cnt;
     uint32_t *dense_cnt;
     int8_t *dense_sig;
@@ -298,26 +299,17 @@ __global__ __launch_bounds__(256) void wave_tile_kernel(const WaveArgs a) {
         uint32_t tot;
         const uint32_t ex = block_excl_scan_256<uint32_t>(mine, reinterpret_cast<uint32_t *>(scr), tot);
         if (tid < ncell) PC[tid] = ex;
-        const uint32_t shard = blockIdx.x & (kShards - 1u);
-        if (tid == 0) {
-            unsigned long long base = 0;
-            if (tot) base = atomicAdd(&a.counters[shard * kShardWords], (unsigned long long)tot);
-            a.tile_off[blockIdx.x] = base;
-            a.tile_cnt[blockIdx.x] = tot;
-            scr[4] = base;
-        }
-        __syncthreads();
-        const unsigned long long base = scr[4];
-        gams_peak_t *const region = a.peaks + (size_t)shard * a.shard_cap;
+        if (tid == 0) a.tile_cnt[blockIdx.x] = tot;
+        const uint32_t base = 0;
+        gams_peak_t *const region = a.peaks + (size_t)blockIdx.x * a.tile_cap;
         if (tot) {
             for (uint32_t r = 0; r < R; ++r) {
                 const uint32_t code = (uint32_t)(sigbits >> (2u * r)) & 3u;
                 const unsigned long long bal = __ballot(code != 0);
                 if (code) {
                     const uint32_t i = w0 + (r << 8) + tid;
-                    const unsigned long long pos =
-                        base + PC[(r << 2) + wv] + __popcll(bal & ((1ull << lane) - 1ull));
-                    if (pos < a.shard_cap) {
+                    const uint32_t pos = base + PC[(r << 2) + wv] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                    if (pos < a.tile_cap) {
                         gams_peak_t pk;
                         pk.ctg = tl.ctg;
                         pk.window = i;
@@ -784,24 +776,16 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
         const uint32_t mine = (uint32_t)__popc(both);
         uint32_t tot;
         const uint32_t ex = block_excl_scan_256<uint32_t>(mine, scr, tot);
-        const uint32_t shard = blockIdx.x & (kShards - 1u);
-        if (tid == 0) {
-            unsigned long long gb = 0;
-            if (tot) gb = atomicAdd(&a.counters[shard * kShardWords], (unsigned long long)tot);
-            a.tile_off[blockIdx.x] = gb;
-            a.tile_cnt[blockIdx.x] = tot;
-            reinterpret_cast<unsigned long long *>(scr + 8)[0] = gb;
-        }
-        __syncthreads();
+        if (tid == 0) a.tile_cnt[blockIdx.x] = tot;
         if (mine) {
-            gams_peak_t *const region = a.peaks + (size_t)shard * a.shard_cap;
-            unsigned long long pos = reinterpret_cast<const unsigned long long *>(scr + 8)[0] + ex;
+            gams_peak_t *const region = a.peaks + (size_t)blockIdx.x * a.tile_cap;
+            uint32_t pos = ex;
             uint32_t bits = both;
             while (bits) {
                 const int q = __ffs((int)bits) - 1;
                 bits &= bits - 1u;
                 const uint32_t code = (crest >> q) & 1u;
-                if (pos < a.shard_cap) {
+                if (pos < a.tile_cap) {
                     gams_peak_t pk;
                     pk.ctg = tl.ctg;
                     pk.window = w0 + base + (uint32_t)q;
@@ -875,8 +859,7 @@ __global__ void wave_serial_kernel(const WaveCtgDev *ctgs, uint32_t n_ctg, const
 __global__ __launch_bounds__(256) void wave_compact_kernel(const WaveCtgDev *ctgs, const WaveTile *tiles,
                                                             uint32_t tw, const uint32_t *dense_cnt,
                                                             const int8_t *dense_sig, gams_peak_t *peaks,
-                                                            uint64_t shard_cap, unsigned long long *counters,
-                                                            unsigned long long *tile_off, uint32_t *tile_cnt) {
+                                                            uint32_t tile_cap, uint32_t *tile_cnt) {
     __shared__ uint32_t PC[132];
     __shared__ uint64_t scr[8];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -899,25 +882,17 @@ __global__ __launch_bounds__(256) void wave_compact_kernel(const WaveCtgDev *ctg
     uint32_t tot;
     const uint32_t ex = block_excl_scan_256<uint32_t>(mine, reinterpret_cast<uint32_t *>(scr), tot);
     if (tid < ncell) PC[tid] = ex;
-    const uint32_t shard = blockIdx.x & (kShards - 1u);
-    if (tid == 0) {
-        unsigned long long base = 0;
-        if (tot) base = atomicAdd(&counters[shard * kShardWords], (unsigned long long)tot);
-        tile_off[blockIdx.x] = base;
-        tile_cnt[blockIdx.x] = tot;
-        scr[4] = base;
-    }
-    __syncthreads();
-    const unsigned long long base = scr[4];
+    if (tid == 0) tile_cnt[blockIdx.x] = tot;
+    const uint32_t base = 0;
     if (!tot) return;
-    peaks += (size_t)shard * shard_cap;
+    peaks += (size_t)blockIdx.x * tile_cap;
     for (uint32_t r = 0; r < R; ++r) {
         const uint32_t code = (uint32_t)(sigbits >> (2u * r)) & 3u;
         const unsigned long long bal = __ballot(code != 0);
         if (code) {
             const uint32_t i = w0 + (r << 8) + tid;
-            const unsigned long long pos = base + PC[(r << 2) + wv] + __popcll(bal & ((1ull << lane) - 1ull));
-            if (pos < shard_cap) {
+            const uint32_t pos = base + PC[(r << 2) + wv] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (pos < tile_cap) {
                 gams_peak_t pk;
                 pk.ctg = tl.ctg;
                 pk.window = i;
@@ -927,6 +902,17 @@ __global__ __launch_bounds__(256) void wave_compact_kernel(const WaveCtgDev *ctg
             }
         }
     }
+}
+
+// Pack the per-tile slots into one dense, (ctg, window)-ordered array: one wave per tile.
+__global__ __launch_bounds__(64) void wave_gather_kernel(const gams_peak_t *slots, uint32_t tile_cap,
+                                                         const uint32_t *tile_cnt, const unsigned long long *tile_off,
+                                                         gams_peak_t *dense) {
+    const uint32_t t = blockIdx.x;
+    const uint32_t n = tile_cnt[t];
+    const gams_peak_t *src = slots + (size_t)t * tile_cap;
+    gams_peak_t *dst = dense + tile_off[t];
+    for (uint32_t i = threadIdx.x; i < n; i += 64u) dst[i] = src[i];
 }
 
 }  // namespace
@@ -950,8 +936,10 @@ struct gams_wave_plan {
     // device
     WaveCtgDev *d_ctgs = nullptr;
     WaveTile *d_tiles = nullptr;
-    gams_peak_t *d_peaks = nullptr;             // kShards regions of shard_cap records
-    uint64_t shard_cap = 0;
+    gams_peak_t *d_peaks = nullptr;             // one slot of tile_cap records per tile
+    uint32_t tile_cap = 0, tile_cap_req = 0;
+    gams_peak_t *d_dense = nullptr;             // packed copy made by gams_wave_peaks
+    uint64_t dense_cap = 0;
     unsigned long long *d_counters = nullptr;   // ring of kCounterRing slots x 4 words, zeroed once per lap
     uint64_t run_idx = 0;
     uint32_t last_slot = 0;
@@ -963,7 +951,6 @@ struct gams_wave_plan {
     int8_t *d_dense_sig = nullptr;
     float *d_filtered = nullptr;
     // host results
-    std::vector<gams_peak_t> h_peaks;
     std::vector<gams_peak_t> h_sorted;
     std::vector<unsigned long long> h_tile_off;
     std::vector<uint32_t> h_tile_cnt;
@@ -1105,6 +1092,15 @@ int wave_upload_geometry(gams_gpu_t *h, gams_wave_plan_t *p) {
     GAMS_HIP(h, hipMalloc(&p->d_tiles, nt * sizeof(WaveTile)));
     GAMS_HIP(h, hipMalloc(&p->d_tile_off, nt * sizeof(unsigned long long)));
     GAMS_HIP(h, hipMalloc(&p->d_tile_cnt, nt * sizeof(uint32_t)));
+    if (p->flags & GAMS_WAVE_PEAKS) {
+        // a slot of tw/8 records per tile (typical density is 1-2 % of the windows); a tile that
+        // overflows makes gams_wave_peaks() regrow the slots to tw records and run again
+        (void)hipFree(p->d_peaks);
+    (void)hipFree(p->d_dense);
+        p->d_peaks = nullptr;
+        p->tile_cap = std::max<uint32_t>(p->tile_cap_req ? p->tile_cap_req : p->tw / 8u, 16u);
+        GAMS_HIP(h, hipMalloc(&p->d_peaks, nt * (size_t)p->tile_cap * sizeof(gams_peak_t)));
+    }
     if (!p->tiles.empty())
         GAMS_HIP(h, hipMemcpy(p->d_tiles, p->tiles.data(), p->tiles.size() * sizeof(WaveTile),
                               hipMemcpyHostToDevice));
@@ -1219,10 +1215,6 @@ int gams_wave_plan_create(gams_gpu_t *h, gams_seqset_t *s, const gams_wave_param
         PLAN_HIP(hipMalloc(&p->d_dense_sig, std::max<uint64_t>(base, 1)));
     }
     if (p->serial) PLAN_HIP(hipMalloc(&p->d_filtered, std::max<uint64_t>(base, 1) * sizeof(float)));
-    if (flags & GAMS_WAVE_PEAKS) {
-        p->shard_cap = base / 16 / kShards + 1024;
-        PLAN_HIP(hipMalloc(&p->d_peaks, p->shard_cap * kShards * sizeof(gams_peak_t)));
-    }
 #undef PLAN_HIP
     *out = p;
     return GAMS_OK;
@@ -1298,11 +1290,10 @@ int gams_wave_run(gams_gpu_t *h, gams_wave_plan_t *p) {
     a.g2 = p->g2;
     a.g3 = p->g3;
     a.peaks = p->d_peaks;
-    a.shard_cap = p->shard_cap;
+    a.tile_cap = p->tile_cap;
     a.counters = p->d_counters + kSlotWords * slot;
     a.const_sig = p->d_const_sig;
     a.stamps = p->d_stamps;
-    a.tile_off = p->d_tile_off;
     a.tile_cnt = p->d_tile_cnt;
     a.dense_cnt = p->d_dense_cnt;
     a.dense_sig = p->d_dense_sig;
@@ -1328,7 +1319,7 @@ int gams_wave_run(gams_gpu_t *h, gams_wave_plan_t *p) {
         if (p->flags & GAMS_WAVE_PEAKS) {
             hipLaunchKernelGGL(wave_compact_kernel, dim3((unsigned)p->tiles.size()), dim3(256), 0, h->compute,
                                p->d_ctgs, p->d_tiles, p->tw, p->d_dense_cnt, p->d_dense_sig, p->d_peaks,
-                               p->shard_cap, p->d_counters + kSlotWords * slot, p->d_tile_off, p->d_tile_cnt);
+                               p->tile_cap, p->d_tile_cnt);
             GAMS_HIP(h, hipGetLastError());
         }
     }
@@ -1340,57 +1331,46 @@ int gams_wave_peaks(gams_gpu_t *h, gams_wave_plan_t *p, const gams_peak_t **peak
     if (!(p->flags & GAMS_WAVE_PEAKS)) return gams_fail(h, GAMS_ESTATE, "wave_peaks: plan has no PEAKS output");
     if (!p->ran) return gams_fail(h, GAMS_ESTATE, "wave_peaks: no run to read");
     GAMS_HIP(h, hipSetDevice(h->device));
+    const size_t nt = p->tiles.size();
     for (int attempt = 0; attempt < 2; ++attempt) {
         GAMS_HIP(h, hipStreamSynchronize(h->compute));
-        std::vector<unsigned long long> cnt(kSlotWords);
-        GAMS_HIP(h, hipMemcpy(cnt.data(), p->d_counters + kSlotWords * p->last_slot,
-                              kSlotWords * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        uint64_t total = 0, worst = 0;
-        uint64_t host_base[kShards];
-        for (uint32_t sh = 0; sh < kShards; ++sh) {
-            host_base[sh] = total;
-            total += cnt[sh * kShardWords];
-            worst = std::max<uint64_t>(worst, cnt[sh * kShardWords]);
+        p->h_tile_cnt.resize(nt);
+        p->h_tile_off.resize(nt);
+        if (nt)
+            GAMS_HIP(h, hipMemcpy(p->h_tile_cnt.data(), p->d_tile_cnt, nt * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        uint64_t total = 0;
+        uint32_t worst = 0;
+        for (size_t t = 0; t < nt; ++t) {
+            p->h_tile_off[t] = total;
+            total += p->h_tile_cnt[t];
+            worst = std::max(worst, p->h_tile_cnt[t]);
         }
-        if (worst > p->shard_cap) {
-            // grow and run again: records past a shard's capacity were dropped
-            (void)hipFree(p->d_peaks);
-            p->d_peaks = nullptr;
-            p->shard_cap = worst + worst / 8 + 1024;
-            GAMS_HIP(h, hipMalloc(&p->d_peaks, p->shard_cap * kShards * sizeof(gams_peak_t)));
-            int rc = gams_wave_run(h, p);
+        if (worst > p->tile_cap) {
+            // some tile signalled more windows than its slot holds: give every tile a slot of
+            // tw records (the maximum possible) and run again
+            p->tile_cap_req = p->tw;
+            int rc = wave_upload_geometry(h, p);
+            if (rc == GAMS_OK) rc = gams_wave_run(h, p);
             if (rc != GAMS_OK) return rc;
             continue;
         }
-        const size_t nt = p->tiles.size();
-        p->h_peaks.resize(total);
         p->h_sorted.resize(total);
-        p->h_tile_off.resize(nt);
-        p->h_tile_cnt.resize(nt);
-        for (uint32_t sh = 0; sh < kShards; ++sh) {
-            const uint64_t c = cnt[sh * kShardWords];
-            if (c)
-                GAMS_HIP(h, hipMemcpyAsync(p->h_peaks.data() + host_base[sh], p->d_peaks + (size_t)sh * p->shard_cap,
-                                           c * sizeof(gams_peak_t), hipMemcpyDeviceToHost, h->compute));
-        }
-        if (nt) {
-            GAMS_HIP(h, hipMemcpyAsync(p->h_tile_off.data(), p->d_tile_off, nt * sizeof(unsigned long long),
+        if (total) {
+            if (total > p->dense_cap) {
+                (void)hipFree(p->d_dense);
+                p->d_dense = nullptr;
+                p->dense_cap = total + total / 4 + 1024;
+                GAMS_HIP(h, hipMalloc(&p->d_dense, p->dense_cap * sizeof(gams_peak_t)));
+            }
+            GAMS_HIP(h, hipMemcpyAsync(p->d_tile_off, p->h_tile_off.data(), nt * sizeof(unsigned long long),
+                                       hipMemcpyHostToDevice, h->compute));
+            hipLaunchKernelGGL(wave_gather_kernel, dim3((unsigned)nt), dim3(64), 0, h->compute, p->d_peaks,
+                               p->tile_cap, p->d_tile_cnt, p->d_tile_off, p->d_dense);
+            GAMS_HIP(h, hipGetLastError());
+            GAMS_HIP(h, hipMemcpyAsync(p->h_sorted.data(), p->d_dense, total * sizeof(gams_peak_t),
                                        hipMemcpyDeviceToHost, h->compute));
-            GAMS_HIP(h, hipMemcpyAsync(p->h_tile_cnt.data(), p->d_tile_cnt, nt * sizeof(uint32_t),
-                                       hipMemcpyDeviceToHost, h->compute));
+            GAMS_HIP(h, hipStreamSynchronize(h->compute));
         }
-        GAMS_HIP(h, hipStreamSynchronize(h->compute));
-        // tiles are in (ctg, window) order; each tile's records are contiguous and ordered
-        // inside the region of shard (tile % kShards)
-        uint64_t o = 0;
-        for (size_t t = 0; t < nt; ++t) {
-            const uint32_t c = p->h_tile_cnt[t];
-            if (!c) continue;
-            std::memcpy(&p->h_sorted[o], &p->h_peaks[host_base[t % kShards] + p->h_tile_off[t]],
-                        (size_t)c * sizeof(gams_peak_t));
-            o += c;
-        }
-        if (o != total) return gams_fail(h, GAMS_EHIP, "wave_peaks: tile counts do not add up");
         *peaks = p->h_sorted.data();
         *n_peaks = total;
         return GAMS_OK;

@@ -187,3 +187,25 @@ def test_guard_band_is_rarely_taken(eng):
     assert n_exact < plan.total_windows * 2e-3, n_exact
     plan.close()
     ss.close()
+
+
+def test_peak_slots_regrow_when_every_window_signals(eng, s288c):
+    # threshold -1: |x - avg| > -std is always true, so each tile holds tile_windows peaks,
+    # far beyond the default slot of tile_windows / 8 records
+    seq = s288c["Mito"]
+    ss = engine.SeqSet(eng, [seq, seq[:30000]])
+    for tile in (0, 256, 3072):
+        plan = engine.WavePlan(eng, ss, 100, 10, 100, -1.0, 1.0, flags=_lib.WAVE_PEAKS, tile_windows=tile)
+        plan.run()
+        pk = plan.peaks()
+        exp = []
+        for c, s in enumerate([seq, seq[:30000]]):
+            ocnt, _, osig = ora.wave_windows(s, 100, 10, 100, -1.0, 1.0)
+            idx = np.flatnonzero(osig)
+            exp += [(c, int(i), int(ocnt[i]), int(osig[i])) for i in idx]
+        got = [(int(r["ctg"]), int(r["window"]), int(r["gc_count"]), int(r["signal"])) for r in pk]
+        assert got == exp and len(got) > 8000
+        plan.run()                         # a second run after the regrow keeps working
+        assert len(plan.peaks()) == len(exp)
+        plan.close()
+    ss.close()
