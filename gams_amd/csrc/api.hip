@@ -30,6 +30,8 @@ int gams_gpu_create(int device, gams_gpu_t **out) {
         return bail(e, "hipStreamCreate(copy)");
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&h->k0)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&h->k1)) != hipSuccess) return bail(e, "hipEventCreate");
     *out = h;
     return GAMS_OK;
 }
@@ -47,6 +49,8 @@ void gams_gpu_destroy(gams_gpu_t *h) {
     }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->k0) (void)hipEventDestroy(h->k0);
+    if (h->k1) (void)hipEventDestroy(h->k1);
     delete h;
 }
 
@@ -82,6 +86,15 @@ int gams_gpu_timer_stop(gams_gpu_t *h, float *ms) {
     GAMS_HIP(h, hipEventRecord(h->ev1, h->compute));
     GAMS_HIP(h, hipEventSynchronize(h->ev1));
     GAMS_HIP(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return GAMS_OK;
+}
+
+int gams_gpu_last_kernel_ms(gams_gpu_t *h, float *ms) {
+    if (!h || !ms) return gams_fail(h, GAMS_EINVAL, "last_kernel_ms: null argument");
+    if (!h->k_valid) return gams_fail(h, GAMS_ESTATE, "last_kernel_ms: no timed call yet");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    GAMS_HIP(h, hipEventSynchronize(h->k1));
+    GAMS_HIP(h, hipEventElapsedTime(ms, h->k0, h->k1));
     return GAMS_OK;
 }
 

@@ -16,6 +16,8 @@ struct gams_gpu {
     hipStream_t compute = nullptr;  // every kernel of the library runs here
     hipStream_t copy = nullptr;     // H2D staging of seq: bytes
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t k0 = nullptr, k1 = nullptr;  // around the kernel of the last query-style call
+    bool k_valid = false;
     int cus = 0;
     uint64_t hbm = 0;
     char arch[64] = {0};

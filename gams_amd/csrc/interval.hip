@@ -260,9 +260,12 @@ int gams_gpu_count(gams_gpu_t *h, gams_index_t *ix, const uint32_t *group, const
     Q_HIP(qb.in(&d_s, qs, nq, h->compute));
     Q_HIP(qb.in(&d_e, qe, nq, h->compute));
     Q_HIP(qb.in(&d_o, (const int32_t *)nullptr, nq, h->compute));
+    Q_HIP(hipEventRecord(h->k0, h->compute));
     hipLaunchKernelGGL(interval_count_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->compute,
                        ix->d_off, ix->d_starts, ix->d_stops, ix->n_groups, d_g, d_s, d_e, nq, d_o);
     Q_HIP(hipGetLastError());
+    Q_HIP(hipEventRecord(h->k1, h->compute));
+    h->k_valid = true;
     Q_HIP(hipMemcpyAsync(count, d_o, nq * sizeof(int32_t), hipMemcpyDeviceToHost, h->compute));
     Q_HIP(hipStreamSynchronize(h->compute));
     return GAMS_OK;
@@ -282,10 +285,13 @@ int gams_gpu_locate(gams_gpu_t *h, gams_index_t *ix, const uint32_t *group, cons
     Q_HIP(qb.in(&d_s, qs, nq, h->compute));
     Q_HIP(qb.in(&d_e, qe, nq, h->compute));
     Q_HIP(qb.in(&d_o, (const int64_t *)nullptr, nq, h->compute));
+    Q_HIP(hipEventRecord(h->k0, h->compute));
     hipLaunchKernelGGL(interval_locate_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->compute,
                        ix->d_off, ix->d_lstart, ix->d_lstop, ix->d_lorig, ix->d_maxlen, ix->n_groups, d_g, d_s,
                        d_e, nq, d_o);
     Q_HIP(hipGetLastError());
+    Q_HIP(hipEventRecord(h->k1, h->compute));
+    h->k_valid = true;
     Q_HIP(hipMemcpyAsync(hit, d_o, nq * sizeof(int64_t), hipMemcpyDeviceToHost, h->compute));
     Q_HIP(hipStreamSynchronize(h->compute));
     return GAMS_OK;
@@ -354,10 +360,13 @@ int gams_gpu_cover(gams_gpu_t *h, gams_spans_t *sp, const uint32_t *group, const
     Q_HIP(qb.in(&d_s, qs, nq, h->compute));
     Q_HIP(qb.in(&d_e, qe, nq, h->compute));
     Q_HIP(qb.in(&d_o, (const float *)nullptr, nq, h->compute));
+    Q_HIP(hipEventRecord(h->k0, h->compute));
     hipLaunchKernelGGL(span_cover_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->compute,
                        sp->d_off, sp->d_lo, sp->d_hi, sp->d_cum, sp->n_groups, d_g, d_cl, d_ch, d_s, d_e, nq,
                        d_o);
     Q_HIP(hipGetLastError());
+    Q_HIP(hipEventRecord(h->k1, h->compute));
+    h->k_valid = true;
     Q_HIP(hipMemcpyAsync(prop, d_o, nq * sizeof(float), hipMemcpyDeviceToHost, h->compute));
     Q_HIP(hipStreamSynchronize(h->compute));
     return GAMS_OK;

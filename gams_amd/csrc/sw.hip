@@ -358,8 +358,11 @@ extern "C" int gams_gpu_sw(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, int32_t 
         cleanup();
         return gams_fail(h, GAMS_EUNSUPPORTED, "gpu_sw: too many feature slots for one launch");
     }
+    SW_HIP(hipEventRecord(h->k0, h->compute));
     hipLaunchKernelGGL(sw_kernel, dim3((unsigned)blocks), dim3(256), 0, h->compute, a);
     SW_HIP(hipGetLastError());
+    SW_HIP(hipEventRecord(h->k1, h->compute));
+    h->k_valid = true;
     SW_HIP(hipMemcpyAsync(rows, d_rows, n_out * sizeof(gams_sw_row_t), hipMemcpyDeviceToHost, h->compute));
     SW_HIP(hipStreamSynchronize(h->compute));
 #undef SW_HIP

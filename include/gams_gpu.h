@@ -58,6 +58,9 @@ int gams_gpu_sync(gams_gpu_t *h);
  * of this library is launched on).  stop() synchronises and returns ms. */
 int gams_gpu_timer_start(gams_gpu_t *h);
 int gams_gpu_timer_stop(gams_gpu_t *h, float *ms);
+/* Device time (HIP events around the kernel, excluding the host<->device copies) of the last
+ * gams_gpu_sw / gams_gpu_count / gams_gpu_locate / gams_gpu_cover call on this handle. */
+int gams_gpu_last_kernel_ms(gams_gpu_t *h, float *ms);
 
 /* window.rs:78-94: number of size/step windows over `len` bases (-1: bad size/step) */
 int64_t gams_window_count(int64_t len, int32_t size, int32_t step);

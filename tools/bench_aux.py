@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Device-time rates of the secondary kernels (sw, locate --count, locate, anno) on synthetic
+inputs shaped like BASELINE configs[2] / configs[4], per GPU share.  Kernel time only
+(gams_gpu_last_kernel_ms: HIP events around the kernel); host<->device copies excluded."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gams_amd import _lib, engine, synth  # noqa: E402
+
+eng = engine.Engine(0)
+lib = eng.lib
+
+
+def kernel_ms():
+    ms = C.c_float()
+    eng.check(lib.gams_gpu_last_kernel_ms(eng.h, C.byref(ms)))
+    return ms.value
+
+
+rng = np.random.default_rng(5)
+
+# ---- sw: 1e5 point features on a 30 Mb chromosome cut in 1-Mb ctgs (config 2 shape) ----
+chrom = synth.chromosome(30_000_000, 9)
+ctgs = synth.gen_ctgs("9", chrom, piece=1000000)
+ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])
+rows_total, ms_total = 0, 0.0
+for rep in range(2):
+    rows_total, ms_total = 0, 0.0
+    for i, c in enumerate(ctgs):
+        nf = 100000 // len(ctgs)
+        fs = np.sort(rng.integers(c["chr_start"], c["chr_end"] + 1, nf)).astype(np.int32)
+        fe = fs.copy()
+        n = C.c_uint64()
+        rows = np.zeros(nf * 41, _lib.SW_ROW_DTYPE)
+        eng.check(lib.gams_gpu_sw(eng.h, ss.p, i, c["chr_start"], fs.ctypes.data, fe.ctypes.data, nf, 100, 20, 500,
+                                  rows.ctypes.data, rows.size, C.byref(n)))
+        rows_total += n.value
+        ms_total += kernel_ms()
+print(f"sw: {rows_total} rows in {ms_total:.3f} ms kernel time -> {rows_total / ms_total / 1e6:.2f} G rows/s, "
+      f"{rows_total * 84 / ms_total / 1e6:.1f} GB/s at 84 B/row")
+
+# ---- locate --count: 1.25e7 stored points + 1.25e7 queries over 4000 ctgs (config 4 per-GPU share) ----
+n_ctg, per = 4000, 1_000_000
+m = 12_500_000
+g_of = np.sort(rng.integers(0, n_ctg, m)).astype(np.uint32)
+off = np.searchsorted(g_of, np.arange(n_ctg + 1)).astype(np.uint64)
+starts = (g_of.astype(np.uint64) % 32 * 0 + rng.integers(1, per, m)).astype(np.uint32)
+stops = starts + 1
+ix = C.c_void_p()
+t0 = time.time()
+eng.check(lib.gams_index_create(eng.h, n_ctg, off.ctypes.data, starts.ctypes.data, stops.ctypes.data, C.byref(ix)))
+print(f"index_create ({m} intervals, {n_ctg} groups): {time.time() - t0:.2f} s host sort + upload")
+nq = 12_500_000
+qg = rng.integers(0, n_ctg, nq).astype(np.uint32)
+qs = rng.integers(1, per, nq).astype(np.uint32)
+qe = qs + rng.integers(1, 2000, nq).astype(np.uint32)
+out = np.zeros(nq, np.int32)
+for name, order in (("unsorted queries", np.arange(nq)), ("queries sorted by (ctg, start)", np.lexsort((qs, qg)))):
+    a, b, c = qg[order].copy(), qs[order].copy(), qe[order].copy()
+    for _ in range(2):
+        eng.check(lib.gams_gpu_count(eng.h, ix, a.ctypes.data, b.ctypes.data, c.ctypes.data, nq, out.ctypes.data))
+    ms = kernel_ms()
+    print(f"count, {name}: {nq / ms / 1e6:.2f} G queries/s, {nq * 16 / ms / 1e6:.1f} GB/s at 16 B/query ({ms:.3f} ms)")
+hit = np.zeros(nq, np.int64)
+for _ in range(2):
+    eng.check(lib.gams_gpu_locate(eng.h, ix, qg.ctypes.data, qs.ctypes.data, qe.ctypes.data, nq, hit.ctypes.data))
+ms = kernel_ms()
+print(f"locate (first overlap), unsorted: {nq / ms / 1e6:.2f} G queries/s ({ms:.3f} ms)")
+lib.gams_index_destroy(eng.h, ix)
+
+# ---- anno: 1e6 spans per chr x 4 chr, 1.25e7 lines ----
+n_chr, n_sp = 4, 1_000_000
+lo_all, hi_all, soff = [], [], [0]
+for _ in range(n_chr):
+    cuts = np.sort(rng.choice(np.arange(1, 2_000_000_000, 97), 2 * n_sp, replace=False))
+    lo_all.append(cuts[0::2].astype(np.int32))
+    hi_all.append((cuts[1::2] - 1).astype(np.int32))
+    soff.append(soff[-1] + n_sp)
+lo = np.concatenate(lo_all)
+hi = np.concatenate(hi_all)
+soff = np.array(soff, np.uint64)
+sp = C.c_void_p()
+eng.check(lib.gams_spans_create(eng.h, n_chr, soff.ctypes.data, lo.ctypes.data, hi.ctypes.data, C.byref(sp)))
+g = rng.integers(0, n_chr, nq).astype(np.uint32)
+s = rng.integers(1, 1_999_000_000, nq).astype(np.int32)
+e = (s + rng.integers(0, 2000, nq)).astype(np.int32)
+cl = (s - s % 1_000_000 + 1).astype(np.int32)
+ch = (cl + 999_999).astype(np.int32)
+prop = np.zeros(nq, np.float32)
+for _ in range(2):
+    eng.check(lib.gams_gpu_cover(eng.h, sp, g.ctypes.data, cl.ctypes.data, ch.ctypes.data, s.ctypes.data,
+                                 e.ctypes.data, nq, prop.ctypes.data))
+ms = kernel_ms()
+print(f"anno cover: {nq / ms / 1e6:.2f} G lines/s, {nq * 16 / ms / 1e6:.1f} GB/s at 16 B/line ({ms:.3f} ms)")
+lib.gams_spans_destroy(eng.h, sp)
