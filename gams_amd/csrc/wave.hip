@@ -331,21 +331,24 @@ __device__ __forceinline__ float readlane_f32(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-// Sequential f32 sum of the 64 lane values of `x` on top of `carry`, in lane order, as a
-// wavefront recurrence: s <- x + wave_shr:1(s), 63 times, lane 0 fed with the carry.  After
-// t steps lanes 0..t hold carry + x_0 + ... + x_l accumulated strictly left to right (f32
-// addition is commutative, so x_l + prefix_{l-1} is the reference's prefix_{l-1} + x_l), and
-// finished lanes no longer change.  One DPP add per element, no scalar round trip.
-__device__ __forceinline__ float seq_add_64(float carry, float x) {
-    float s = x + carry;   // only lane 0 keeps this; the others are overwritten below
+// Sequential f32 sum of the first `STEPS + 1` lane values of `x` on top of `carry`, in lane
+// order, as a wavefront recurrence: s <- wave_shr:1(s) + x, lane 0 keeping x_0 + carry (a DPP
+// lane without a source is left unchanged with bound_ctrl off).  After t steps lanes 0..t hold
+// carry + x_0 + ... + x_l accumulated strictly left to right (f32 addition is commutative, so
+// prefix_{l-1} + x_l is what the reference computes), and finished lanes no longer change.
+// One v_add_f32_dpp per element; the two s_nop cover the VALU-write -> DPP-read hazard.
+template <int STEPS>
+__device__ __forceinline__ float seq_add_lanes(float carry, float x) {
+    float s = x + carry;
 #pragma unroll
-    for (int t = 0; t < 63; ++t) {
-        const float prev = __int_as_float(
-            __builtin_amdgcn_update_dpp(__float_as_int(carry), __float_as_int(s), 0x138, 0xf, 0xf, false));
-        s = x + prev;       // lane 0: x_0 + carry again (bound lanes take `old` = carry)
-    }
-    return readlane_f32(s, 63);
+    for (int t = 0; t < STEPS; ++t)
+        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf"
+                     : "+v"(s)
+                     : "v"(x));
+    return readlane_f32(s, STEPS);
 }
+
+__device__ __forceinline__ float seq_add_64(float carry, float x) { return seq_add_lanes<63>(carry, x); }
 
 __device__ __noinline__ int exact_signal_wave(const uint8_t *K, uint32_t tj, uint32_t ti, uint32_t n,
                                               float fsize, float thr) {
@@ -992,7 +995,7 @@ void wave_guard_band(const gams_wave_params_t &p, float g[4]) {
     const double gam = 1.01 * (n + 1.0) * u / (1.0 - (n + 1.0) * u);  // f32 sequential mean
     const double kap = std::sqrt(n / (n - 1.0));
     const double eta = 1.01 * ((n + 3.0) / 2.0 + 2.0) * u;              // sq sum, /, sqrt, *thr
-    const double safety = 2.0;
+    const double safety = 1.5;
     g[1] = (float)(safety * (gam + 2.0 * u + thr * kap * gam * (1.0 + eta)));
     g[2] = (float)(safety * (eta + 8.0 * u));
     g[3] = (float)(safety * 3.0 * u);
