@@ -8,25 +8,25 @@
 //
 // One workgroup = one tile of consecutive windows of one ctg, plus the halo of
 // lag+1 windows in front of it whose gc values the z-score of the tile's first
-// windows needs (z-score state never crosses a ctg: wave.rs:294-297).
+// windows needs (z-score state never crosses a ctg: wave.rs:294-297).  Workgroups
+// never communicate; every tile writes its peaks into its own fixed slot.
 //
-//   phase 1  tile bytes HBM -> registers (16 B/lane, coalesced), SWAR classify
-//            G/C/g/c -> 16-bit mask per 16-B chunk -> LDS
-//   phase 1b workgroup scan of the chunk popcounts -> PM[chunk] = prefix<<16 | mask
-//   phase 2  k[w] = P(w*step+size) - P(w*step)  (integer, bit-exact), and
-//            exclusive prefixes Q1 = sum k, Q2 = sum k^2 over the tile's windows
-//   phase 3  per window: S1, S2 over the lag windows the reference averages
-//            (stat.rs:51-52: filtered[i-1-lag .. i-1), or [0,lag) for i == lag),
-//            integer decision |n*k - S1| vs thr*sqrt(n*V/(n-1)) with a rigorous
-//            guard band; windows inside the band are re-evaluated in the
-//            reference's exact f32 order (three sequential passes), so signals
-//            are bit-identical to the reference.
-//   phase 4  ordered compaction of signal != 0 windows / dense rows.
+// Two tile kernels share that scheme:
+//   wave_fast_kernel<W,SIZE,STEP,LAG>  8-bit counts, 32-bit variance math (every BASELINE
+//       configuration): 1-bit-per-base stream in LDS, rolling window counts, rolling
+//       S1/S2, branch-free integer decision with a rigorous guard band, wave-cooperative
+//       exact-order f32 re-evaluation of the windows inside the band.  See its header.
+//   wave_tile_kernel<KT,WIDE>          any size/lag up to 65535: chunk prefix PM (prefix<<16 |
+//       mask), k[w] = P(w*step+size) - P(w*step), prefix arrays Q1 = sum k, Q2 = sum k^2,
+//       same decision + guard band, scalar exact path.
+// Signals are bit-identical to thresholding_algo in both (the guard band only decides
+// which windows take the exact path).
 //
 // influence != 1 makes filtered[] (stat.rs:42) a true serial recurrence: those
-// runs use wave_serial_kernel (one lane per ctg, exact f32 order).
+// runs use wave_serial_kernel (one lane per ctg, exact f32 order) on the counts of a
+// counts-only tile pass, then wave_compact_kernel.
 //
-// Compile with -ffp-contract=off: the exact path must not fuse (x-m)*(x-m)+acc.
+// Compile with -ffp-contract=off: the exact paths must not fuse (x-m)*(x-m)+acc.
 
 #include "common.hpp"
 
@@ -407,22 +407,26 @@ __device__ __forceinline__ void push_gt_i32(uint32_t &acc, int32_t x, int32_t y)
 }
 
 // =============================================================================
-// wave_fast_kernel<W>: the same tile algorithm specialised for 8-bit counts
-// (size <= 255) and 32-bit variance math (lag*size <= 65535, lag*size^2 < 2^24),
-// i.e. every BASELINE configuration.  256 threads, W windows per thread.
+// wave_fast_kernel<W,SIZE,STEP,LAG>: the tile algorithm for 8-bit counts (size <= 255),
+// step <= 32 and 32-bit variance math (lag*size <= 65535, lag*size^2 < 2^24), i.e. every
+// BASELINE configuration.  256 threads, W windows per thread, tile = 256*W windows.
 //
-//   phase 1/1b as above.
-//   phase 2  interleaved over the tile's lag+1+256*W window slots: k -> K[] (u8).
-//            Slot idx holds window vb+idx with vb = w0-lag-1; windows before the
-//            ctg start (first tile only) read as k = 0.
-//   phase 3  thread t owns windows w0 + t*W + [0,W).  It sums the lag counts in
-//            front of its first window once (v_dot4 on packed bytes: S1 = sum k,
-//            S2 = sum k^2) and then rolls: S(q+1) = S(q) - K[tW+q] + K[tW+q+lag].
-//            All K traffic is whole dwords at an odd dword stride between lanes
-//            (W/4 in {1,3,5}): conflict-free.  Window i == lag averages windows
-//            [0,lag) like i == lag+1 (stat.rs:30-31 vs :51-52): it uses the
-//            rolled sums.
-//   phase 4  per-thread peak counts -> one workgroup scan -> one atomic per tile.
+//   phase 1  tile bytes HBM -> registers (16 B/lane, coalesced) -> G/C/g/c flags
+//            (v_bitop3, v_add, v_bitop3 per dword; v_dot4 gathers 4 flags) -> 16-bit mask
+//            per 16-B chunk -> LDS bit stream BM (1 bit per base).
+//   phase 2  window counts, rolling over the bit stream: k(w+1) = k(w) + popc(step bits
+//            entering) - popc(step bits leaving); stored as bytes K[].  Slot idx holds
+//            window vb+idx with vb = w0-lag-1; windows before the ctg start read as 0.
+//   phase 3  thread t owns windows w0 + t*W + [0,W).  It sums the lag counts in front of
+//            its first window once (v_dot4 on packed bytes: S1 = sum k, S2 = sum k^2) and
+//            then rolls: S(q+1) = S(q) - K[tW+q] + K[tW+q+lag].  All K traffic is whole
+//            dwords at an odd dword stride between lanes (W/4 in {1,3,5}): conflict-free.
+//            Branch-free integer decision; three bits per window go into carry-chain
+//            accumulators.  Window i == lag (averages [0,lag): stat.rs:30-31) is redone by
+//            its owner.  Windows inside the guard band: const_sig table (homopolymer runs)
+//            or exact_signal_wave.
+//   phase 4  dense rows through LDS (coalesced stores) and/or per-thread peak counts ->
+//            one workgroup scan -> records in window order into the tile's fixed slot.
 // =============================================================================
 // __launch_bounds__(256, 8): 8 waves per SIMD = 8 workgroups per CU, i.e. at most 64 VGPRs.
 // Interleaved A/B (tools/ab.py) on 384 Mb: W = 12 runs 115 -> 105 us with the cap.

@@ -1,0 +1,70 @@
+"""Randomised parameter sweep of the wave path on the GPU against the oracle: sizes, steps
+(smaller than, equal to and larger than the size), lags and thresholds drawn at random, ragged
+ctg lengths, every kernel variant (baked / run-time fast kernels, general kernel, serial path)."""
+import numpy as np
+import pytest
+
+from gams_amd import _lib, engine
+from oracle import oracle as ora
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = engine.Engine(0)
+    yield e
+    e.close()
+
+
+def random_seq(rng, n):
+    # blocks of different GC richness, soft-masked stretches, N runs, a homopolymer
+    s = np.empty(n, np.uint8)
+    pos = 0
+    while pos < n:
+        ln = int(rng.integers(200, 6000))
+        gc = rng.uniform(0.15, 0.75)
+        blk = np.where(rng.random(ln) < gc, rng.choice([0x47, 0x43], ln), rng.choice([0x41, 0x54], ln)).astype(np.uint8)
+        if rng.random() < 0.3:
+            blk |= 0x20
+        if rng.random() < 0.1:
+            blk[:] = rng.choice([0x4E, 0x41, 0x67])
+        s[pos:pos + ln] = blk[:n - pos]
+        pos += ln
+    return s
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_random_parameters(eng, seed):
+    rng = np.random.default_rng(1000 + seed)
+    size = int(rng.choice([1, 7, 10, 50, 64, 100, 100, 100, 128, 200, 255, 256, 300, 1000]))
+    step = int(rng.choice([1, 2, 5, 10, 10, 10, 16, 31, 32, 33, 50, 64, 100, 150]))
+    lag = int(rng.choice([2, 3, 10, 33, 50, 100, 100, 127, 128, 200, 400]))
+    thr = float(rng.choice([0.5, 1.0, 2.0, 2.5, 3.0, 3.0, 3.5, 5.0]))
+    infl = float(rng.choice([1.0, 1.0, 1.0, 1.0, 0.5, 0.0]))
+    n_ctg = int(rng.integers(1, 5))
+    need = size + (lag + 5) * step
+    seqs = [random_seq(rng, int(need + rng.integers(0, 40 * need // 10 + 5000))) for _ in range(n_ctg)]
+    ss = engine.SeqSet(eng, seqs)
+    try:
+        plan = engine.WavePlan(eng, ss, size, step, lag, thr, infl, flags=_lib.WAVE_PEAKS | _lib.WAVE_DENSE)
+    except _lib.GamsError as e:
+        assert e.code == _lib.EUNSUPPORTED, e        # only a halo beyond the 64-KB tile may be refused
+        assert (lag + 1) * step + size + 256 * step > 65000
+        ss.close()
+        return
+    plan.run()
+    pk = plan.peaks()
+    exp = []
+    for c, s in enumerate(seqs):
+        ocnt, _, osig = ora.wave_windows(s, size, step, lag, thr, infl)
+        cnt, sig = plan.dense(c)
+        assert np.array_equal(cnt, ocnt), (size, step, lag, thr, infl)
+        bad = np.flatnonzero(sig.astype(np.int32) != osig)
+        assert bad.size == 0, (size, step, lag, thr, infl, bad[:5])
+        idx = np.flatnonzero(osig)
+        exp += [(c, int(i), int(ocnt[i]), int(osig[i])) for i in idx]
+    got = [(int(r["ctg"]), int(r["window"]), int(r["gc_count"]), int(r["signal"])) for r in pk]
+    assert got == exp, (size, step, lag, thr, infl)
+    plan.close()
+    ss.close()
