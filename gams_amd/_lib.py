@@ -70,6 +70,8 @@ PROTOTYPES = {
     "gams_spans_create": (C.c_int, [_VP, C.c_uint32, _VP, _VP, _VP, _PP]),
     "gams_spans_destroy": (None, [_VP, _VP]),
     "gams_gpu_cover": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_uint64, _VP]),
+    "gams_gpu_valid_spans": (C.c_int, [_VP, _VP, C.c_uint64, C.c_int32, C.c_int32, _VP, _VP, C.c_uint64,
+                                       C.POINTER(C.c_uint64)]),
 }
 
 _lib = None

@@ -44,6 +44,8 @@ def load():
     L.gams_host_anno.restype = C.c_void_p
     L.gams_host_anno.argtypes = [C.c_void_p, C.c_uint32, sp, sp, ip, ip, C.c_char_p, C.c_char_p, C.c_int,
                                  C.c_char_p, C.c_uint32, C.c_uint32]
+    L.gams_host_gen.restype = C.c_void_p
+    L.gams_host_gen.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32]
     L.gams_host_fmt_f32.restype = C.c_void_p
     L.gams_host_fmt_f32.argtypes = [C.c_float]
     L.gams_host_range_roundtrip.restype = C.c_void_p
@@ -113,6 +115,12 @@ def anno(eng, ctgs, runlists, lines, header=False, prefix="", idx_id=1, idx_rang
     rl = "\n".join(f"{k}\t{v}" for k, v in runlists.items())
     return _take(load().gams_host_anno(eng.h, n, ids, chrs, st.ctypes.data, en.ctypes.data, rl.encode(),
                                        "\n".join(lines).encode(), int(header), prefix.encode(), idx_id, idx_range))
+
+
+def gen(eng, chr_id, seq, piece=500000, fill=50, min_len=5000):
+    """ctg rows (id, range, chr_id, chr_start, chr_end, chr_strand, length) of one chromosome."""
+    a = np.ascontiguousarray(np.frombuffer(seq, np.uint8) if not isinstance(seq, np.ndarray) else seq)
+    return _take(load().gams_host_gen(eng.h, chr_id.encode(), a.ctypes.data, a.size, piece, fill, min_len))
 
 
 def fmt_f32(v):

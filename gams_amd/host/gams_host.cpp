@@ -469,6 +469,44 @@ std::string Locator::locate(const std::vector<std::string> &rgs, bool is_count) 
 }
 
 // ---------------------------------------------------------------------------
+// gen
+// ---------------------------------------------------------------------------
+std::vector<Ctg> gen_ctgs(gams_gpu_t *h, const std::string &chr_id, const uint8_t *seq, uint64_t len,
+                          const GenArgs &a) {
+    uint64_t n = 0;
+    check(h, gams_gpu_valid_spans(h, seq, len, a.fill, a.min, nullptr, nullptr, 0, &n));
+    std::vector<int32_t> lo(n ? n : 1), hi(n ? n : 1);
+    check(h, gams_gpu_valid_spans(h, seq, len, a.fill, a.min, lo.data(), hi.data(), n, &n));
+    std::vector<Ctg> out;
+    int32_t serial = 0;
+    for (uint64_t i = 0; i < n; ++i) {                                 // gen.rs:108-126
+        int64_t pos = lo[i];
+        const int64_t max = hi[i];
+        std::vector<std::pair<int64_t, int64_t>> cur;
+        while (max - pos + 1 > a.piece) {
+            cur.emplace_back(pos, pos + a.piece - 1);
+            pos += a.piece;
+        }
+        if (cur.empty())
+            cur.emplace_back(pos, max);
+        else
+            cur.back().second = max;                                   // the last piece absorbs the remainder
+        for (auto &r : cur) {                                          // gen.rs:131-150
+            Ctg c;
+            c.id = "ctg:" + chr_id + ":" + std::to_string(++serial);
+            c.chr_id = chr_id;
+            c.chr_start = (int32_t)r.first;
+            c.chr_end = (int32_t)r.second;
+            c.chr_strand = "+";
+            c.length = c.chr_end - c.chr_start + 1;
+            c.range = chr_id + ":" + runlist(r.first, r.second);
+            out.push_back(c);
+        }
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------
 // anno
 // ---------------------------------------------------------------------------
 namespace {

@@ -100,6 +100,14 @@ private:
     std::map<std::string, uint32_t> rg_group_;    // ctg id -> group of the rg index
 };
 
+// gen.rs:81-157 for one chromosome: ambiguous-base scan (device), fill, excise, --piece split;
+// ctg ids "ctg:{chr}:{serial}" with serial from 1 (gen.rs:133-134).  `seq` is the whole chromosome.
+struct GenArgs {            // defaults of src/cmd_gams/gen.rs:26-49
+    int32_t piece = 500000, fill = 50, min = 5000;
+};
+std::vector<Ctg> gen_ctgs(gams_gpu_t *h, const std::string &chr_id, const uint8_t *seq, uint64_t len,
+                          const GenArgs &a);
+
 // anno.rs:95-142; `sets` = runlists per chr (sorted disjoint spans)
 struct Runlist {
     std::vector<int32_t> lo, hi;

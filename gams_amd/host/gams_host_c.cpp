@@ -165,6 +165,23 @@ char *gams_host_anno(gams_gpu_t *h, uint32_t n, const char *const *ids, const ch
     });
 }
 
+// gen.rs:81-157 for one chromosome; rows "id\trange\tchr_id\tchr_start\tchr_end\tchr_strand\tlength"
+// (the columns of `gams tsv -s "ctg:*"`, tests/S288c/ctg.tsv)
+char *gams_host_gen(gams_gpu_t *h, const char *chr_id, const uint8_t *seq, uint64_t len, int32_t piece,
+                    int32_t fill, int32_t min_len) {
+    return guarded([&] {
+        gams::GenArgs a;
+        a.piece = piece;
+        a.fill = fill;
+        a.min = min_len;
+        std::string out;
+        for (const gams::Ctg &c : gams::gen_ctgs(h, chr_id, seq, len, a))
+            out += c.id + "\t" + c.range + "\t" + c.chr_id + "\t" + std::to_string(c.chr_start) + "\t" +
+                   std::to_string(c.chr_end) + "\t" + c.chr_strand + "\t" + std::to_string(c.length) + "\n";
+        return out;
+    });
+}
+
 // formatting helpers exposed for CPU-only tests
 char *gams_host_fmt_f32(float v) { return dup(gams::fmt_f32(v)); }
 char *gams_host_range_roundtrip(const char *s) {

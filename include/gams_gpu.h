@@ -19,6 +19,7 @@
  *   gams_gpu_count            src/libs/utils.rs:24-36       (count_rg -> Lapper::count)
  *   gams_gpu_locate           src/libs/utils.rs:7-22        (find_one_idx -> Lapper::find().next())
  *   gams_gpu_cover            src/cmd_gams/anno.rs:128-139  (IntSpan intersect cardinalities)
+ *   gams_gpu_valid_spans      src/cmd_gams/gen.rs:86-104    (ambiguous-base scan, fill, excise)
  */
 #ifndef GAMS_GPU_H
 #define GAMS_GPU_H
@@ -187,6 +188,14 @@ int gams_gpu_cover(gams_gpu_t *h, gams_spans_t *sp, const uint32_t *group,
                    const int32_t *clip_lo, const int32_t *clip_hi,
                    const int32_t *qs, const int32_t *qe, uint64_t nq,
                    float *prop);
+
+/* ---- gen: valid regions of a chromosome (first "next" row of SURVEY section 8f) ---- */
+/* gen.rs:86-104: bases other than A C G T a c g t are ambiguous; the valid set is their
+ * complement after fill(fill-1) and excise(min_len).  Writes up to `cap` spans (1-based,
+ * inclusive, ascending); *n_spans is the full count (call with cap = 0 to size). */
+int gams_gpu_valid_spans(gams_gpu_t *h, const uint8_t *seq, uint64_t len, int32_t fill,
+                         int32_t min_len, int32_t *span_lo, int32_t *span_hi, uint64_t cap,
+                         uint64_t *n_spans);
 
 #ifdef __cplusplus
 }

@@ -587,3 +587,64 @@ float ora_anno_prop(const int32_t *span_lo, const int32_t *span_hi, size_t ns,
     int64_t total = (int64_t)re - rs + 1;
     return (float)(int32_t)card / (float)(int32_t)total;             /* :138 */
 }
+
+/* ------------------------------------------------------------------------ */
+/* cmd_gams/gen.rs:81-126: valid regions -> --piece chunks                   */
+/* ------------------------------------------------------------------------ */
+int64_t ora_gen_regions(const uint8_t *seq, int64_t len, int32_t piece, int32_t fill,
+                        int32_t min_len, int32_t *out_start, int32_t *out_end, int64_t cap) {
+    /* valid spans = complement of the ambiguous bases (gen.rs:86-102) */
+    int64_t nsp = 0, csp = 1024;
+    int64_t *lo = (int64_t *)malloc(sizeof(int64_t) * csp), *hi = (int64_t *)malloc(sizeof(int64_t) * csp);
+    int64_t run = -1;
+    for (int64_t i = 0; i <= len; ++i) {
+        int ok = 0;
+        if (i < len) {
+            uint8_t b = seq[i];
+            ok = b == 'A' || b == 'C' || b == 'G' || b == 'T' || b == 'a' || b == 'c' || b == 'g' || b == 't';
+        }
+        if (ok && run < 0) run = i;
+        if (!ok && run >= 0) {
+            /* fill(fill-1): a hole of at most fill-1 bases joins the previous span (gen.rs:103) */
+            if (nsp > 0 && (run + 1) - hi[nsp - 1] - 1 <= (int64_t)fill - 1) {
+                hi[nsp - 1] = i;
+            } else {
+                if (nsp == csp) {
+                    csp *= 2;
+                    lo = (int64_t *)realloc(lo, sizeof(int64_t) * csp);
+                    hi = (int64_t *)realloc(hi, sizeof(int64_t) * csp);
+                }
+                lo[nsp] = run + 1;
+                hi[nsp] = i;
+                ++nsp;
+            }
+            run = -1;
+        }
+    }
+    int64_t n = 0;
+    for (int64_t s = 0; s < nsp; ++s) {
+        if (hi[s] - lo[s] + 1 < (int64_t)min_len) continue; /* excise(min): gen.rs:104 */
+        int64_t pos = lo[s], max = hi[s];
+        int64_t first = n;
+        while (max - pos + 1 > piece) { /* gen.rs:112-116 */
+            if (n < cap) {
+                out_start[n] = (int32_t)pos;
+                out_end[n] = (int32_t)(pos + piece - 1);
+            }
+            ++n;
+            pos += piece;
+        }
+        if (n == first) { /* gen.rs:118-120 */
+            if (n < cap) {
+                out_start[n] = (int32_t)pos;
+                out_end[n] = (int32_t)max;
+            }
+            ++n;
+        } else if (n - 1 < cap) { /* gen.rs:121-123: the last piece absorbs the remainder */
+            out_end[n - 1] = (int32_t)max;
+        }
+    }
+    free(lo);
+    free(hi);
+    return n;
+}

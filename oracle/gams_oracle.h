@@ -106,6 +106,12 @@ int32_t ora_lapper_count(const uint32_t *sorted_starts,
 float ora_anno_prop(const int32_t *span_lo, const int32_t *span_hi, size_t ns,
                     int32_t ctg_s, int32_t ctg_e, int32_t rs, int32_t re);
 
+/* ---- cmd_gams/gen.rs:81-126 ------------------------------------------- */
+/* ctg regions of one chromosome: ambiguous-base scan, fill(fill-1), excise(min), --piece
+ * split (last piece absorbs the remainder).  1-based inclusive; returns the count. */
+int64_t ora_gen_regions(const uint8_t *seq, int64_t len, int32_t piece, int32_t fill,
+                        int32_t min_len, int32_t *out_start, int32_t *out_end, int64_t cap);
+
 /* ---- Rust float Display ------------------------------------------------ */
 /* `{}` for f32: shortest round-trip digits, positional.  Returns length. */
 int ora_fmt_f32(float v, char *out /* >= 64 bytes */);

@@ -73,6 +73,8 @@ def lib():
         L.ora_lapper_count.argtypes = [u32p, u32p, C.c_size_t, C.c_uint32, C.c_uint32]
         L.ora_anno_prop.restype = C.c_float
         L.ora_anno_prop.argtypes = [i32p, i32p, C.c_size_t] + [C.c_int32] * 4
+        L.ora_gen_regions.restype = C.c_int64
+        L.ora_gen_regions.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, C.c_int64]
         L.ora_fmt_f32.restype = C.c_int
         L.ora_fmt_f32.argtypes = [C.c_float, C.c_char_p]
         L.ora_free.restype = None
@@ -231,3 +233,13 @@ def fmt_f32(v):
     b = C.create_string_buffer(64)
     lib().ora_fmt_f32(v, b)
     return b.value.decode()
+
+
+def gen_regions(seq, piece=500000, fill=50, min_len=5000):
+    """[(start, end)] of the ctgs `gams gen` cuts one chromosome into (gen.rs:81-126)."""
+    a = _u8(seq)
+    n = lib().ora_gen_regions(a.ctypes.data, a.size, piece, fill, min_len, None, None, 0)
+    s = np.zeros(max(n, 1), np.int32)
+    e = np.zeros(max(n, 1), np.int32)
+    lib().ora_gen_regions(a.ctypes.data, a.size, piece, fill, min_len, _ptr(s, C.c_int32), _ptr(e, C.c_int32), n)
+    return [(int(s[i]), int(e[i])) for i in range(n)]

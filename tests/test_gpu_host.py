@@ -248,3 +248,32 @@ def test_anno_random_vs_oracle(eng):
     lines.insert(9, f"ctg:1:1\tnot_a_range\tx")                        # dropped (anno.rs:123-125)
     out = host.anno(eng, ctgs, runlists, lines, header=False, idx_id=1, idx_range=2)
     assert out.splitlines() == exp
+
+
+# ---- gen (first "next" row of SURVEY section 8f) ------------------------------------------------
+def test_command_gen(eng, s288c):
+    """tests/cli.rs:112-146: piece 100000 -> ctg:I:1, ctg:I:2, ctg:Mito:1; rows of tests/S288c/ctg.tsv."""
+    rows = host.gen(eng, "I", s288c["I"], piece=100000) + host.gen(eng, "Mito", s288c["Mito"], piece=100000)
+    got = rows.splitlines()
+    assert [r.split("\t")[0] for r in got] == ["ctg:I:1", "ctg:I:2", "ctg:Mito:1"]
+    assert sorted(got) == sorted(helpers.read_lines("ctg.tsv")[1:])
+    one = host.gen(eng, "I", s288c["I"], piece=500000).splitlines()
+    assert one == ["ctg:I:1\tI:1-230218\tI\t1\t230218\t+\t230218"]
+
+
+def test_gen_ambiguous_regions_vs_oracle(eng):
+    from gams_amd import synth
+
+    rng = np.random.default_rng(17)
+    chrom = synth.chromosome(3_000_000, 41).copy()
+    # N runs on both sides of the fill limit, other IUPAC codes, runs at both ends, short valid islands
+    for pos, ln in [(0, 30), (5000, 49), (9000, 50), (20000, 51), (100000, 7000), (107100, 40), (107200, 60),
+                    (2_999_990, 10), (1_500_000, 1), (1_500_016, 16), (1_600_000 - 3, 35)]:
+        chrom[pos:pos + ln] = ord("N")
+    chrom[400000:400003] = np.frombuffer(b"RYk", np.uint8)
+    chrom[rng.integers(0, chrom.size, 200)] = rng.integers(0, 256, 200)     # arbitrary bytes
+    for piece, fill, mn in [(500000, 50, 5000), (100000, 50, 5000), (1000000, 1, 1), (250000, 100, 20000)]:
+        rows = host.gen(eng, "7", chrom, piece=piece, fill=fill, min_len=mn).splitlines()
+        got = [(int(r.split("\t")[3]), int(r.split("\t")[4])) for r in rows]
+        assert got == ora.gen_regions(chrom, piece, fill, mn), (piece, fill, mn)
+        assert [r.split("\t")[0] for r in rows] == [f"ctg:7:{i + 1}" for i in range(len(rows))]
