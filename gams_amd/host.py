@@ -44,6 +44,14 @@ def load():
     L.gams_host_anno.restype = C.c_void_p
     L.gams_host_anno.argtypes = [C.c_void_p, C.c_uint32, sp, sp, ip, ip, C.c_char_p, C.c_char_p, C.c_int,
                                  C.c_char_p, C.c_uint32, C.c_uint32]
+    L.gams_host_locate_seq.restype = C.c_void_p
+    L.gams_host_locate_seq.argtypes = [C.c_void_p, C.c_uint32, sp, sp, ip, ip, C.c_char_p, C.c_char_p]
+    L.gams_host_read_range.restype = C.c_void_p
+    L.gams_host_read_range.argtypes = [C.c_void_p, C.c_uint32, sp, sp, ip, ip, C.c_char_p]
+    L.gams_host_decode_gz.restype = C.c_void_p
+    L.gams_host_decode_gz.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.gams_host_encode_gz.restype = C.c_void_p
+    L.gams_host_encode_gz.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.gams_host_gen.restype = C.c_void_p
     L.gams_host_gen.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32]
     L.gams_host_fmt_f32.restype = C.c_void_p
@@ -121,6 +129,42 @@ def gen(eng, chr_id, seq, piece=500000, fill=50, min_len=5000):
     """ctg rows (id, range, chr_id, chr_start, chr_end, chr_strand, length) of one chromosome."""
     a = np.ascontiguousarray(np.frombuffer(seq, np.uint8) if not isinstance(seq, np.ndarray) else seq)
     return _take(load().gams_host_gen(eng.h, chr_id.encode(), a.ctypes.data, a.size, piece, fill, min_len))
+
+
+def locate_seq(eng, ctgs, rgs):
+    """`gams locate --seq`: FASTA text; ctgs carry their gunzipped sequence in c["seq"]."""
+    n, ids, chrs, st, en = _ctg_arrays(ctgs)
+    seq_lines = "\n".join(f"{c['id']}\t{bytes(c['seq']).decode()}" for c in ctgs)
+    return _take(load().gams_host_locate_seq(eng.h, n, ids, chrs, st.ctypes.data, en.ctypes.data,
+                                             "\n".join(rgs).encode(), seq_lines.encode()))
+
+
+def read_range(eng, ctgs, lines):
+    """utils.rs:39-67 incl. the drop-first-per-ctg quirk: list of (ctg_id, range string)."""
+    n, ids, chrs, st, en = _ctg_arrays(ctgs)
+    out = _take(load().gams_host_read_range(eng.h, n, ids, chrs, st.ctypes.data, en.ctypes.data,
+                                            "\n".join(lines).encode()))
+    return [tuple(r.split("\t")) for r in out.splitlines()]
+
+
+def decode_gz(blob):
+    n = C.c_uint64()
+    p = load().gams_host_decode_gz(blob, len(blob), C.byref(n))
+    if not p:
+        raise HostError(load().gams_host_last_code(), load().gams_host_last_error().decode(errors="replace"))
+    out = C.string_at(p, n.value)
+    load().gams_host_free(p)
+    return out
+
+
+def encode_gz(data):
+    n = C.c_uint64()
+    p = load().gams_host_encode_gz(data, len(data), C.byref(n))
+    if not p:
+        raise HostError(-1, "encode_gz failed")
+    out = C.string_at(p, n.value)
+    load().gams_host_free(p)
+    return out
 
 
 def fmt_f32(v):

@@ -9,6 +9,8 @@
 #include <cstring>
 #include <numeric>
 
+#include <zlib.h>
+
 namespace gams {
 
 namespace {
@@ -465,6 +467,97 @@ std::string Locator::locate(const std::vector<std::string> &rgs, bool is_count) 
     check(h_, gams_gpu_count(h_, rg_ix_, grp.data(), qs.data(), qe.data(), who.size(), cnt.data()));
     for (size_t j = 0; j < who.size(); ++j)
         out += rgs[src[who[j]]] + "\t" + std::to_string(cnt[j]) + "\n";  // locate.rs:137
+    return out;
+}
+
+std::string Locator::locate_seq(const std::vector<std::string> &rgs,
+                                const std::map<std::string, std::string> &seq_of) {
+    std::vector<Range> valid;
+    std::vector<size_t> src;
+    for (size_t i = 0; i < rgs.size(); ++i) {
+        Range r = Range::from_str(rgs[i]);
+        if (!r.valid) continue;
+        r.strand.clear();
+        valid.push_back(r);
+        src.push_back(i);
+    }
+    std::vector<std::string> ctg_ids = find(valid);
+    std::string out;
+    for (size_t k = 0; k < valid.size(); ++k) {
+        if (ctg_ids[k].empty()) continue;
+        const Ctg *c = ctg(ctg_ids[k]);
+        auto it = seq_of.find(ctg_ids[k]);
+        if (!c || it == seq_of.end()) throw Error(GAMS_EINVAL, "locate --seq: no sequence for " + ctg_ids[k]);
+        const int64_t from = (int64_t)valid[k].start - c->chr_start + 1;   // locate.rs:128-129
+        const int64_t to = (int64_t)valid[k].end - c->chr_start + 1;
+        if (from < 1 || to > (int64_t)it->second.size() || to < from)
+            throw Error(GAMS_EINVAL, "locate --seq: range outside " + ctg_ids[k] +
+                                         " (the reference panics, locate.rs:133)");
+        out += ">" + rgs[src[k]] + "\n" + it->second.substr((size_t)from - 1, (size_t)(to - from + 1)) + "\n";
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------
+// loaders' bucketing (utils.rs:39-67) and the gzip framing of `seq:` (redis.rs:149-161)
+// ---------------------------------------------------------------------------
+std::map<std::string, std::vector<Range>> read_range(Locator &loc, const std::vector<std::string> &lines) {
+    std::vector<Range> valid;
+    for (const std::string &ln : lines) {
+        Range r = Range::from_str(ln);                                  // utils.rs:50-53
+        if (r.valid) valid.push_back(r);
+    }
+    std::vector<std::string> ids = loc.find(valid);                     // utils.rs:55 (strand is not used by the lookup)
+    std::map<std::string, std::vector<Range>> ranges_of;
+    for (size_t k = 0; k < valid.size(); ++k) {
+        if (ids[k].empty()) continue;                                   // utils.rs:56-58
+        auto it = ranges_of.find(ids[k]);
+        if (it == ranges_of.end())
+            ranges_of[ids[k]];                                          // or_default(): the first range is dropped
+        else
+            it->second.push_back(valid[k]);                             // and_modify(push)
+    }
+    return ranges_of;
+}
+
+std::string decode_gz(const uint8_t *bytes, size_t n) {
+    z_stream zs{};
+    if (inflateInit2(&zs, 15 + 16) != Z_OK) throw Error(GAMS_EINVAL, "decode_gz: inflateInit2 failed");
+    zs.next_in = const_cast<Bytef *>(bytes);
+    zs.avail_in = (uInt)n;
+    std::string out;
+    char buf[1 << 16];
+    int rc;
+    do {
+        zs.next_out = reinterpret_cast<Bytef *>(buf);
+        zs.avail_out = sizeof buf;
+        rc = inflate(&zs, Z_NO_FLUSH);
+        if (rc != Z_OK && rc != Z_STREAM_END) {
+            inflateEnd(&zs);
+            throw Error(GAMS_EINVAL, "decode_gz: corrupt gzip member");
+        }
+        out.append(buf, sizeof buf - zs.avail_out);
+    } while (rc != Z_STREAM_END);
+    inflateEnd(&zs);
+    return out;
+}
+
+std::string encode_gz(const uint8_t *bytes, size_t n) {
+    z_stream zs{};
+    if (deflateInit2(&zs, Z_BEST_SPEED, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK)
+        throw Error(GAMS_EINVAL, "encode_gz: deflateInit2 failed");
+    zs.next_in = const_cast<Bytef *>(bytes);
+    zs.avail_in = (uInt)n;
+    std::string out;
+    char buf[1 << 16];
+    int rc;
+    do {
+        zs.next_out = reinterpret_cast<Bytef *>(buf);
+        zs.avail_out = sizeof buf;
+        rc = deflate(&zs, Z_FINISH);
+        out.append(buf, sizeof buf - zs.avail_out);
+    } while (rc != Z_STREAM_END);
+    deflateEnd(&zs);
     return out;
 }
 

@@ -88,6 +88,8 @@ public:
     std::vector<std::string> find(const std::vector<Range> &rgs);
     // locate output: "{rg}\t{ctg_id}\n" or with count "{rg}\t{count}\n" (locate.rs:135-140)
     std::string locate(const std::vector<std::string> &rgs, bool is_count);
+    // locate --seq (locate.rs:124-134): ">{rg}\n{bases}\n"; seq_of maps ctg id -> gunzipped seq
+    std::string locate_seq(const std::vector<std::string> &rgs, const std::map<std::string, std::string> &seq_of);
     const Ctg *ctg(const std::string &id) const;
 
 private:
@@ -99,6 +101,17 @@ private:
     gams_index_t *rg_ix_ = nullptr;
     std::map<std::string, uint32_t> rg_group_;    // ctg id -> group of the rg index
 };
+
+class Locator;
+
+// src/libs/redis.rs:149-161: the `seq:` values are gzip members (flate2, Compression::fast)
+std::string decode_gz(const uint8_t *bytes, size_t n);
+std::string encode_gz(const uint8_t *bytes, size_t n);
+
+// src/libs/utils.rs:39-67 read_range: locate every valid range and bucket it by ctg, INCLUDING
+// the reference's quirk: `.entry(k).and_modify(push).or_default()` only creates the bucket for
+// the first range of a ctg, so that range is dropped (tests/cli.rs:250,301: 79 lines -> 69).
+std::map<std::string, std::vector<Range>> read_range(Locator &loc, const std::vector<std::string> &lines);
 
 // gen.rs:81-157 for one chromosome: ambiguous-base scan (device), fill, excise, --piece split;
 // ctg ids "ctg:{chr}:{serial}" with serial from 1 (gen.rs:133-134).  `seq` is the whole chromosome.

@@ -121,6 +121,55 @@ char *gams_host_locate(gams_gpu_t *h, uint32_t n, const char *const *ids, const 
     });
 }
 
+// locate --seq (locate.rs:124-134).  seq_lines: "ctg_id\tbases" rows.
+char *gams_host_locate_seq(gams_gpu_t *h, uint32_t n, const char *const *ids, const char *const *chrs,
+                           const int32_t *starts, const int32_t *ends, const char *rgs, const char *seq_lines) {
+    return guarded([&] {
+        gams::Locator loc(h, make_ctgs(n, ids, chrs, starts, ends));
+        std::map<std::string, std::string> seq_of;
+        for (const std::string &ln : split_lines(seq_lines)) {
+            size_t tab = ln.find('\t');
+            if (tab != std::string::npos) seq_of[ln.substr(0, tab)] = ln.substr(tab + 1);
+        }
+        return loc.locate_seq(split_lines(rgs), seq_of);
+    });
+}
+
+// utils.rs:39-67 read_range with the drop-first quirk: rows "ctg_id\trange" in bucket order
+char *gams_host_read_range(gams_gpu_t *h, uint32_t n, const char *const *ids, const char *const *chrs,
+                           const int32_t *starts, const int32_t *ends, const char *lines) {
+    return guarded([&] {
+        gams::Locator loc(h, make_ctgs(n, ids, chrs, starts, ends));
+        std::vector<std::string> first_cols;
+        for (const std::string &ln : split_lines(lines)) first_cols.push_back(ln.substr(0, ln.find('\t')));
+        std::string out;
+        for (auto &kv : gams::read_range(loc, first_cols))
+            for (const gams::Range &r : kv.second) out += kv.first + "\t" + r.to_string() + "\n";
+        return out;
+    });
+}
+
+// gzip framing of seq: values (redis.rs:149-161); *out_len receives the length
+char *gams_host_decode_gz(const uint8_t *bytes, uint64_t n, uint64_t *out_len) {
+    return guarded([&] {
+        std::string s = gams::decode_gz(bytes, n);
+        if (out_len) *out_len = s.size();
+        return s;
+    });
+}
+char *gams_host_encode_gz(const uint8_t *bytes, uint64_t n, uint64_t *out_len) {
+    try {
+        std::string s = gams::encode_gz(bytes, n);
+        if (out_len) *out_len = s.size();
+        char *p = (char *)std::malloc(s.size() + 1);
+        if (p) std::memcpy(p, s.data(), s.size());
+        return p;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+
 // utils.rs:7-22 for many ranges: one ctg id (or empty) per line
 char *gams_host_find(gams_gpu_t *h, uint32_t n, const char *const *ids, const char *const *chrs,
                      const int32_t *starts, const int32_t *ends, const char *rgs) {

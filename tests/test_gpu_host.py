@@ -277,3 +277,22 @@ def test_gen_ambiguous_regions_vs_oracle(eng):
         got = [(int(r.split("\t")[3]), int(r.split("\t")[4])) for r in rows]
         assert got == ora.gen_regions(chrom, piece, fill, mn), (piece, fill, mn)
         assert [r.split("\t")[0] for r in rows] == [f"ctg:7:{i + 1}" for i in range(len(rows))]
+
+
+def test_read_range_quirk_and_rg_counts(eng, s288c):
+    """tests/cli.rs:235-253, 285-304 through the C++ read_range: 79 lines -> 71 located -> 69 kept."""
+    ctgs = all_ctgs(s288c)
+    recs = host.read_range(eng, ctgs, helpers.read_lines("spo11_hot.rg"))
+    assert len(recs) == 69
+    assert recs == rg_records(eng, ctgs, "spo11_hot.rg")
+    assert {c for c, _ in recs} == {"ctg:I:1", "ctg:I:2"}
+
+
+def test_locate_seq(eng, s288c):
+    """locate --seq (locate.rs:124-134); tests/cli.rs:160-171 names the expected bases."""
+    ctgs = all_ctgs(s288c)
+    out = host.locate_seq(eng, ctgs, ["I:1000-1002", "I:1000-1010", "II:1000-1100", "I(+):100001-100010"])
+    lines = out.splitlines()
+    assert lines[:4] == [">I:1000-1002", "ATA", ">I:1000-1010", "ATACAATTATA"]
+    assert lines[4] == ">I(+):100001-100010" and lines[5] == s288c["I"][100000:100010].decode()
+    assert len(lines) == 6

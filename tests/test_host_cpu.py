@@ -34,3 +34,21 @@ def test_fmt_f32_matches_rust_display_and_the_oracle():
 ])
 def test_range_grammar(s, exp):
     assert host.range_roundtrip(s) == exp
+
+
+def test_gzip_framing_of_seq_values():
+    """redis.rs:149-161: seq: values are gzip members; any RFC 1952 codec must interoperate."""
+    import gzip
+    import os
+
+    import helpers
+
+    raw = helpers.load_s288c()["Mito"][:50000]
+    assert host.decode_gz(gzip.compress(raw, 1)) == raw          # what flate2 fast() writes
+    assert gzip.decompress(host.encode_gz(raw)) == raw           # what flate2 GzDecoder reads
+    assert host.decode_gz(host.encode_gz(b"")) == b""
+    with open(os.path.join(helpers.S288C, "genome.fa.gz"), "rb") as fh:
+        blob = fh.read()
+    assert host.decode_gz(blob) == gzip.decompress(blob)         # the reference's own fixture
+    with pytest.raises(host.HostError):
+        host.decode_gz(b"not a gzip member")
