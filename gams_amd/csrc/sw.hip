@@ -248,6 +248,14 @@ __global__ __launch_bounds__(256) void sw_kernel(const SwArgs a) {
     a.rows[row] = r;
 }
 
+// peak (src/cmd_gams/peak.rs:79) / any caller of cache_gc_content: one lane per range
+__global__ __launch_bounds__(256) void range_gc_kernel(const SwArgs a, const int32_t *rs, const int32_t *re,
+                                                       uint32_t n, float *gc) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    gc[q] = round4(range_gc(a, rs[q], re[q]));                          // utils.rs:157-161
+}
+
 }  // namespace
 
 // lazily built per seqset; owned by the seqset (freed in gams_seqset_destroy)
@@ -366,6 +374,57 @@ extern "C" int gams_gpu_sw(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, int32_t 
     SW_HIP(hipMemcpyAsync(rows, d_rows, n_out * sizeof(gams_sw_row_t), hipMemcpyDeviceToHost, h->compute));
     SW_HIP(hipStreamSynchronize(h->compute));
 #undef SW_HIP
+    cleanup();
+    return GAMS_OK;
+}
+
+// gc_content (round4) of arbitrary chromosome ranges inside ctg i: gams::cache_gc_content
+// (src/libs/utils.rs:141-162) as `gams peak` uses it (src/cmd_gams/peak.rs:79).
+extern "C" int gams_gpu_range_gc(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, int32_t chr_start,
+                                 const int32_t *range_start, const int32_t *range_end, uint32_t n, float *gc) {
+    if (!h || !s || (n && (!range_start || !range_end || !gc)))
+        return gams_fail(h, GAMS_EINVAL, "gpu_range_gc: null argument");
+    if (i >= s->n_ctg) return gams_fail(h, GAMS_EINVAL, "gpu_range_gc: ctg index out of range");
+    if (s->len[i] == 0 || s->len[i] > 0x7fffffffu) return gams_fail(h, GAMS_EINVAL, "gpu_range_gc: ctg length out of range");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    if (n == 0) return GAMS_OK;
+    int rc = gams_seqset_gcindex(h, s);
+    if (rc != GAMS_OK) return rc;
+    int32_t *d_rs = nullptr, *d_re = nullptr;
+    float *d_gc = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_rs);
+        (void)hipFree(d_re);
+        (void)hipFree(d_gc);
+    };
+#define R_HIP(call)                                                                            \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            cleanup();                                                                         \
+            return gams_fail(h, GAMS_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+        }                                                                                      \
+    } while (0)
+    R_HIP(hipMalloc(&d_rs, n * sizeof(int32_t)));
+    R_HIP(hipMalloc(&d_re, n * sizeof(int32_t)));
+    R_HIP(hipMalloc(&d_gc, n * sizeof(float)));
+    R_HIP(hipMemcpyAsync(d_rs, range_start, n * sizeof(int32_t), hipMemcpyHostToDevice, h->compute));
+    R_HIP(hipMemcpyAsync(d_re, range_end, n * sizeof(int32_t), hipMemcpyHostToDevice, h->compute));
+    SwArgs a{};
+    a.pm = s->gcindex->d_pm;
+    a.seg = s->gcindex->d_seg;
+    a.seq_off = s->off[i];
+    a.len = s->len[i];
+    a.chr_start = chr_start;
+    a.chr_end = chr_start + (int32_t)s->len[i] - 1;
+    R_HIP(hipEventRecord(h->k0, h->compute));
+    hipLaunchKernelGGL(range_gc_kernel, dim3((n + 255) / 256), dim3(256), 0, h->compute, a, d_rs, d_re, n, d_gc);
+    R_HIP(hipGetLastError());
+    R_HIP(hipEventRecord(h->k1, h->compute));
+    h->k_valid = true;
+    R_HIP(hipMemcpyAsync(gc, d_gc, n * sizeof(float), hipMemcpyDeviceToHost, h->compute));
+    R_HIP(hipStreamSynchronize(h->compute));
+#undef R_HIP
     cleanup();
     return GAMS_OK;
 }

@@ -52,6 +52,8 @@ def load():
     L.gams_host_decode_gz.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.gams_host_encode_gz.restype = C.c_void_p
     L.gams_host_encode_gz.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.gams_host_peak.restype = C.c_void_p
+    L.gams_host_peak.argtypes = [C.c_void_p, C.c_uint32, sp, sp, ip, ip, C.POINTER(C.c_void_p), C.c_char_p]
     L.gams_host_gen.restype = C.c_void_p
     L.gams_host_gen.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32]
     L.gams_host_fmt_f32.restype = C.c_void_p
@@ -165,6 +167,16 @@ def encode_gz(data):
     out = C.string_at(p, n.value)
     load().gams_host_free(p)
     return out
+
+
+def peak(eng, ctgs, lines):
+    """`gams peak` over the rows of a wave TSV: TSV of the Peak fields (data.rs:30-43)."""
+    n, ids, chrs, st, en = _ctg_arrays(ctgs)
+    bufs = [np.ascontiguousarray(np.frombuffer(c["seq"], np.uint8) if not isinstance(c["seq"], np.ndarray)
+                                 else c["seq"]) for c in ctgs]
+    seqs = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in bufs])
+    return _take(load().gams_host_peak(eng.h, n, ids, chrs, st.ctypes.data, en.ctypes.data, seqs,
+                                       "\n".join(lines).encode()))
 
 
 def fmt_f32(v):

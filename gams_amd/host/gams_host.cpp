@@ -520,6 +520,92 @@ std::map<std::string, std::vector<Range>> read_range(Locator &loc, const std::ve
     return ranges_of;
 }
 
+std::map<std::string, std::vector<std::pair<Range, std::string>>> read_peak(Locator &loc,
+                                                                          const std::vector<std::string> &lines) {
+    std::vector<Range> valid;
+    std::vector<std::string> sig;
+    for (const std::string &ln : lines) {
+        std::vector<std::string> parts;
+        size_t b = 0;
+        for (;;) {
+            size_t e = ln.find('\t', b);
+            parts.push_back(ln.substr(b, e == std::string::npos ? std::string::npos : e - b));
+            if (e == std::string::npos) break;
+            b = e + 1;
+        }
+        Range r = Range::from_str(parts[0]);                            // utils.rs:96-99
+        if (!r.valid) continue;
+        if (parts.size() < 3) throw Error(GAMS_EINVAL, "read_peak: a row has no signal column (the reference panics, utils.rs:102)");
+        r.strand.clear();                                               // utils.rs:100
+        valid.push_back(r);
+        sig.push_back(parts[2]);
+    }
+    std::vector<std::string> ids = loc.find(valid);
+    std::map<std::string, std::vector<std::pair<Range, std::string>>> peaks_of;
+    for (size_t k = 0; k < valid.size(); ++k) {
+        if (ids[k].empty()) continue;
+        auto it = peaks_of.find(ids[k]);
+        if (it == peaks_of.end())
+            peaks_of[ids[k]];                                           // utils.rs:109-112: first one dropped
+        else
+            it->second.emplace_back(valid[k], sig[k]);
+    }
+    return peaks_of;
+}
+
+std::vector<Peak> peak_records(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq,
+                               const std::vector<std::pair<Range, std::string>> &peaks) {
+    std::vector<Peak> out(peaks.size());
+    if (peaks.empty()) return out;
+    uint32_t len = (uint32_t)(ctg.chr_end - ctg.chr_start + 1);
+    SeqSetGuard sg{h};
+    check(h, gams_seqset_create(h, 1, &len, &sg.s));
+    check(h, gams_seqset_upload(h, sg.s, 0, seq));
+    std::vector<int32_t> rs(peaks.size()), re(peaks.size());
+    for (size_t i = 0; i < peaks.size(); ++i) {
+        rs[i] = peaks[i].first.start;
+        re[i] = peaks[i].first.end;
+        if (rs[i] < ctg.chr_start || re[i] > ctg.chr_end || re[i] < rs[i])
+            throw Error(GAMS_EINVAL, "peak: " + peaks[i].first.to_string() + " is not inside " + ctg.id +
+                                         " (the reference panics on the slice, utils.rs:155)");
+    }
+    std::vector<float> gc(peaks.size());
+    check(h, gams_gpu_range_gc(h, sg.s, 0, ctg.chr_start, rs.data(), re.data(), (uint32_t)peaks.size(), gc.data()));
+    for (size_t i = 0; i < peaks.size(); ++i) {                         // peak.rs:65-95
+        Peak &p = out[i];
+        p.id = "peak:" + ctg.id + ":" + std::to_string(i + 1);
+        p.range = peaks[i].first.to_string();
+        p.length = re[i] - rs[i] + 1;
+        p.signal = peaks[i].second;
+        p.gc = gc[i];
+    }
+    // left (peak.rs:112-133)
+    std::string prev_signal = out.front().signal;
+    float prev_gc = out.front().gc;
+    int32_t prev_end = ctg.chr_start;
+    for (size_t i = 0; i < out.size(); ++i) {
+        out[i].left_wave_length = rs[i] - prev_end + 1;
+        out[i].left_amplitude = std::fabs(out[i].gc - prev_gc);
+        out[i].left_signal = prev_signal;
+        prev_signal = out[i].signal;
+        prev_end = re[i];
+        prev_gc = out[i].gc;
+    }
+    // right (peak.rs:135-157)
+    std::string next_signal = out.back().signal;
+    float next_gc = out.back().gc;
+    int32_t next_start = ctg.chr_end;
+    for (size_t i = out.size(); i-- > 0;) {
+        out[i].right_wave_length = next_start - re[i] + 1;
+        out[i].right_amplitude = std::fabs(out[i].gc - next_gc);
+        out[i].right_signal = next_signal;
+        next_signal = out[i].signal;
+        next_start = rs[i];
+        next_gc = out[i].gc;
+    }
+    return out;
+}
+
 std::string decode_gz(const uint8_t *bytes, size_t n) {
     z_stream zs{};
     if (inflateInit2(&zs, 15 + 16) != Z_OK) throw Error(GAMS_EINVAL, "decode_gz: inflateInit2 failed");

@@ -113,6 +113,24 @@ std::string encode_gz(const uint8_t *bytes, size_t n);
 // the first range of a ctg, so that range is dropped (tests/cli.rs:250,301: 79 lines -> 69).
 std::map<std::string, std::vector<Range>> read_range(Locator &loc, const std::vector<std::string> &lines);
 
+// src/libs/data.rs:30-43
+struct Peak {
+    std::string id, range, signal;
+    int32_t length = 0;
+    float gc = 0.0f;
+    int32_t left_wave_length = 0, right_wave_length = 0;
+    float left_amplitude = 0.0f, right_amplitude = 0.0f;
+    std::string left_signal, right_signal;
+};
+// src/libs/utils.rs:83-116 read_peak: rows of a wave TSV (range \t gc \t signal) bucketed by ctg,
+// strand stripped, with the same drop-first-per-ctg quirk as read_range; header / invalid rows skipped.
+std::map<std::string, std::vector<std::pair<Range, std::string>>> read_peak(Locator &loc,
+                                                                          const std::vector<std::string> &lines);
+// src/cmd_gams/peak.rs:47-158 for one ctg: gc of every peak range (device), then the left /
+// right wavelength, amplitude and neighbour signal.  Serials start at 1 (a fresh cnt:peak:).
+std::vector<Peak> peak_records(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq,
+                               const std::vector<std::pair<Range, std::string>> &peaks);
+
 // gen.rs:81-157 for one chromosome: ambiguous-base scan (device), fill, excise, --piece split;
 // ctg ids "ctg:{chr}:{serial}" with serial from 1 (gen.rs:133-134).  `seq` is the whole chromosome.
 struct GenArgs {            // defaults of src/cmd_gams/gen.rs:26-49

@@ -149,6 +149,29 @@ char *gams_host_read_range(gams_gpu_t *h, uint32_t n, const char *const *ids, co
     });
 }
 
+// `gams peak` (peak.rs:24-177) for a set of ctgs: `lines` = rows of a wave TSV.  Output rows, per ctg in
+// id order: id, range, length, gc, signal, left_wave_length, left_amplitude, left_signal,
+// right_wave_length, right_amplitude, right_signal (the fields of gams::Peak, data.rs:30-43).
+char *gams_host_peak(gams_gpu_t *h, uint32_t n, const char *const *ids, const char *const *chrs,
+                     const int32_t *starts, const int32_t *ends, const uint8_t *const *seqs, const char *lines) {
+    return guarded([&] {
+        std::vector<gams::Ctg> ctgs = make_ctgs(n, ids, chrs, starts, ends);
+        gams::Locator loc(h, ctgs);
+        auto peaks_of = gams::read_peak(loc, split_lines(lines));
+        std::string out;
+        for (auto &kv : peaks_of) {
+            uint32_t slot = 0;
+            while (slot < n && ctgs[slot].id != kv.first) ++slot;
+            for (const gams::Peak &p : gams::peak_records(h, ctgs[slot], seqs[slot], kv.second))
+                out += p.id + "\t" + p.range + "\t" + std::to_string(p.length) + "\t" + gams::fmt_f32(p.gc) + "\t" +
+                       p.signal + "\t" + std::to_string(p.left_wave_length) + "\t" + gams::fmt_f32(p.left_amplitude) +
+                       "\t" + p.left_signal + "\t" + std::to_string(p.right_wave_length) + "\t" +
+                       gams::fmt_f32(p.right_amplitude) + "\t" + p.right_signal + "\n";
+        }
+        return out;
+    });
+}
+
 // gzip framing of seq: values (redis.rs:149-161); *out_len receives the length
 char *gams_host_decode_gz(const uint8_t *bytes, uint64_t n, uint64_t *out_len) {
     return guarded([&] {

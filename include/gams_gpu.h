@@ -156,6 +156,12 @@ int gams_gpu_sw(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, int32_t chr_start,
                 int32_t size, int32_t max, int32_t resize, gams_sw_row_t *rows,
                 uint64_t cap, uint64_t *n_rows);
 
+/* gc_content (round4, utils.rs:141-162) of n chromosome ranges inside ctg i: what `gams peak`
+ * asks per merged peak (peak.rs:79; second "next" row of SURVEY section 8f). */
+int gams_gpu_range_gc(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, int32_t chr_start,
+                      const int32_t *range_start, const int32_t *range_end, uint32_t n,
+                      float *gc);
+
 /* ---- sorted-interval index (replaces rust_lapper `idx:`) ---------------- */
 /* m intervals [start, stop) (stop = end+1, redis.rs:245-248,291-294) grouped
  * in `n_groups` groups (one per ctg for idx:rg:, one per chr for idx:ctg:);

@@ -648,3 +648,71 @@ int64_t ora_gen_regions(const uint8_t *seq, int64_t len, int32_t piece, int32_t 
     free(hi);
     return n;
 }
+
+/* ------------------------------------------------------------------------ */
+/* cmd_gams/peak.rs:65-158 for one ctg: peaks given in bucket order          */
+/* ------------------------------------------------------------------------ */
+char *ora_peak_rows(const char *ctg_id, const char *chr_id, int32_t chr_start, int32_t chr_end,
+                    const uint8_t *seq, const int32_t *p_start, const int32_t *p_end,
+                    const char *const *p_signal, size_t np) {
+    sbuf out = {0};
+    sb_reserve(&out, 16);
+    out.p[0] = 0;
+    if (np == 0) return out.p;
+    float *gc = (float *)malloc(sizeof(float) * np);
+    int32_t *lw = (int32_t *)malloc(sizeof(int32_t) * np), *rw = (int32_t *)malloc(sizeof(int32_t) * np);
+    float *la = (float *)malloc(sizeof(float) * np), *ra = (float *)malloc(sizeof(float) * np);
+    const char **ls = (const char **)malloc(sizeof(char *) * np), **rs = (const char **)malloc(sizeof(char *) * np);
+    for (size_t i = 0; i < np; ++i) gc[i] = ora_range_gc_content(seq, chr_start, p_start[i], p_end[i]); /* :79 */
+    const char *prev_signal = p_signal[0];                             /* :112-133 */
+    float prev_gc = gc[0];
+    int32_t prev_end = chr_start;
+    for (size_t i = 0; i < np; ++i) {
+        lw[i] = p_start[i] - prev_end + 1;
+        la[i] = fabsf(gc[i] - prev_gc);
+        ls[i] = prev_signal;
+        prev_signal = p_signal[i];
+        prev_end = p_end[i];
+        prev_gc = gc[i];
+    }
+    const char *next_signal = p_signal[np - 1];                        /* :135-157 */
+    float next_gc = gc[np - 1];
+    int32_t next_start = chr_end;
+    for (size_t i = np; i-- > 0;) {
+        rw[i] = next_start - p_end[i] + 1;
+        ra[i] = fabsf(gc[i] - next_gc);
+        rs[i] = next_signal;
+        next_signal = p_signal[i];
+        next_start = p_start[i];
+        next_gc = gc[i];
+    }
+    for (size_t i = 0; i < np; ++i) {
+        sb_puts(&out, "peak:");
+        sb_puts(&out, ctg_id);
+        sb_puts(&out, ":");
+        sb_puti(&out, (long long)i + 1);
+        sb_puts(&out, "\t");
+        sb_range(&out, chr_id, p_start[i], p_end[i]);
+        sb_puts(&out, "\t");
+        sb_puti(&out, p_end[i] - p_start[i] + 1);
+        sb_puts(&out, "\t");
+        sb_putf(&out, gc[i]);
+        sb_puts(&out, "\t");
+        sb_puts(&out, p_signal[i]);
+        sb_puts(&out, "\t");
+        sb_puti(&out, lw[i]);
+        sb_puts(&out, "\t");
+        sb_putf(&out, la[i]);
+        sb_puts(&out, "\t");
+        sb_puts(&out, ls[i]);
+        sb_puts(&out, "\t");
+        sb_puti(&out, rw[i]);
+        sb_puts(&out, "\t");
+        sb_putf(&out, ra[i]);
+        sb_puts(&out, "\t");
+        sb_puts(&out, rs[i]);
+        sb_puts(&out, "\n");
+    }
+    free(gc); free(lw); free(rw); free(la); free(ra); free(ls); free(rs);
+    return out.p;
+}

@@ -112,6 +112,13 @@ float ora_anno_prop(const int32_t *span_lo, const int32_t *span_hi, size_t ns,
 int64_t ora_gen_regions(const uint8_t *seq, int64_t len, int32_t piece, int32_t fill,
                         int32_t min_len, int32_t *out_start, int32_t *out_end, int64_t cap);
 
+/* ---- cmd_gams/peak.rs:65-158 ------------------------------------------ */
+/* TSV rows of the Peak records of one ctg (fields of data.rs:30-43), peaks in bucket order.
+ * PARITY UNPINNED upstream: the reference's tests only check a stderr line (tests/cli.rs:366-382). */
+char *ora_peak_rows(const char *ctg_id, const char *chr_id, int32_t chr_start, int32_t chr_end,
+                    const uint8_t *seq, const int32_t *p_start, const int32_t *p_end,
+                    const char *const *p_signal, size_t np);
+
 /* ---- Rust float Display ------------------------------------------------ */
 /* `{}` for f32: shortest round-trip digits, positional.  Returns length. */
 int ora_fmt_f32(float v, char *out /* >= 64 bytes */);

@@ -75,6 +75,9 @@ def lib():
         L.ora_anno_prop.argtypes = [i32p, i32p, C.c_size_t] + [C.c_int32] * 4
         L.ora_gen_regions.restype = C.c_int64
         L.ora_gen_regions.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, C.c_int64]
+        L.ora_peak_rows.restype = C.c_void_p
+        L.ora_peak_rows.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p, i32p, i32p,
+                                    C.POINTER(C.c_char_p), C.c_size_t]
         L.ora_fmt_f32.restype = C.c_int
         L.ora_fmt_f32.argtypes = [C.c_float, C.c_char_p]
         L.ora_free.restype = None
@@ -243,3 +246,14 @@ def gen_regions(seq, piece=500000, fill=50, min_len=5000):
     e = np.zeros(max(n, 1), np.int32)
     lib().ora_gen_regions(a.ctypes.data, a.size, piece, fill, min_len, _ptr(s, C.c_int32), _ptr(e, C.c_int32), n)
     return [(int(s[i]), int(e[i])) for i in range(n)]
+
+
+def peak_rows(ctg_id, chr_id, chr_start, chr_end, seq, peaks):
+    """peaks: list of (start, end, signal string) in bucket order (peak.rs:65-158)."""
+    a = _u8(seq)
+    n = len(peaks)
+    ps = np.array([p[0] for p in peaks], np.int32)
+    pe = np.array([p[1] for p in peaks], np.int32)
+    sg = (C.c_char_p * max(n, 1))(*[p[2].encode() for p in peaks])
+    return _take_str(lib().ora_peak_rows(ctg_id.encode(), chr_id.encode(), chr_start, chr_end, a.ctypes.data,
+                                         _ptr(ps, C.c_int32), _ptr(pe, C.c_int32), sg, n))

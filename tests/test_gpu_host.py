@@ -296,3 +296,28 @@ def test_locate_seq(eng, s288c):
     assert lines[:4] == [">I:1000-1002", "ATA", ">I:1000-1010", "ATACAATTATA"]
     assert lines[4] == ">I(+):100001-100010" and lines[5] == s288c["I"][100000:100010].decode()
     assert len(lines) == 6
+
+
+# ---- peak (second "next" row of SURVEY section 8f; PARITY UNPINNED upstream) ----------------------
+def test_command_peak(eng, s288c):
+    """`gams peak tests/S288c/I.peaks.tsv` (tests/cli.rs:366-382 only asserts a stderr line).
+    Every field is compared with the oracle's restatement of peak.rs:65-158, on the ctg layout the
+    fixture was made with (piece 500000, README.md:155-172)."""
+    ctgs = helpers.gen_ctgs("I", s288c["I"], piece=500000)
+    lines = helpers.read_lines("I.peaks.tsv")
+    got = host.peak(eng, ctgs, lines)
+    # read_peak (utils.rs:83-116): header row invalid, strand dropped, first peak of each ctg dropped
+    peaks = []
+    for ln in lines[1:]:
+        parts = ln.split("\t")
+        chr_id, s, e = helpers.parse_range(parts[0].replace("(+)", ""))
+        peaks.append((s, e, parts[2]))
+    c = ctgs[0]
+    exp = ora.peak_rows(c["id"], c["chr_id"], c["chr_start"], c["chr_end"], c["seq"], peaks[1:])
+    assert got == exp
+    rows = got.splitlines()
+    assert len(rows) == 115 and rows[0].startswith("peak:ctg:I:1:1\tI:3091-3210\t120\t")
+    assert all(len(r.split("\t")) == 11 for r in rows)
+    # a peak range that leaves its ctg (fixture ranges on the piece-100000 layout) is the reference's panic
+    with pytest.raises(host.HostError):
+        host.peak(eng, all_ctgs(s288c), lines)
