@@ -331,24 +331,28 @@ __device__ __forceinline__ float readlane_f32(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-// Sequential f32 sum of the first `STEPS + 1` lane values of `x` on top of `carry`, in lane
-// order, as a wavefront recurrence: s <- wave_shr:1(s) + x, lane 0 keeping x_0 + carry (a DPP
-// lane without a source is left unchanged with bound_ctrl off).  After t steps lanes 0..t hold
-// carry + x_0 + ... + x_l accumulated strictly left to right (f32 addition is commutative, so
-// prefix_{l-1} + x_l is what the reference computes), and finished lanes no longer change.
-// One v_add_f32_dpp per element; the two s_nop cover the VALU-write -> DPP-read hazard.
-template <int STEPS>
-__device__ __forceinline__ float seq_add_lanes(float carry, float x) {
-    float s = x + carry;
-#pragma unroll
-    for (int t = 0; t < STEPS; ++t)
-        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf"
+// Sequential f32 sum of the first `m` lane values of `x` (m <= 64, wave-uniform) on top of
+// `carry`, in lane order.  Row by row (16 lanes): s <- row_shr:1(s) + x fifteen times, the row's
+// lane 0 keeping x + carry (a DPP lane without a source is left unchanged with bound_ctrl off);
+// after t steps lanes 0..t of the row hold carry + x_0 + ... + x_l accumulated strictly left to
+// right (f32 addition is commutative: prefix_{l-1} + x_l is what the reference computes) and
+// finished lanes no longer change.  The row's last lane is the next row's carry.  All four
+// rows run the instruction stream, only the current one matters.  One v_add_f32_dpp per
+// element; wave_shr:1 would need no row loop but measured ~25 cycles per dependent step.
+#define GAMS_SEQ_STEP "s_nop 1\n\tv_add_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ float seq_add_lanes(float carry, float x, uint32_t m) {
+    for (uint32_t r = 0; r * 16u < m; ++r) {
+        float s = x + carry;   // lane 0 of every row; lanes past m hold x = 0
+        asm volatile(GAMS_SEQ_STEP GAMS_SEQ_STEP GAMS_SEQ_STEP GAMS_SEQ_STEP GAMS_SEQ_STEP GAMS_SEQ_STEP
+                         GAMS_SEQ_STEP GAMS_SEQ_STEP GAMS_SEQ_STEP GAMS_SEQ_STEP GAMS_SEQ_STEP GAMS_SEQ_STEP
+                             GAMS_SEQ_STEP GAMS_SEQ_STEP GAMS_SEQ_STEP
                      : "+v"(s)
                      : "v"(x));
-    return readlane_f32(s, STEPS);
+        carry = readlane_f32(s, (int)(r * 16u + 15u));
+    }
+    return carry;
 }
-
-__device__ __forceinline__ float seq_add_64(float carry, float x) { return seq_add_lanes<63>(carry, x); }
+#undef GAMS_SEQ_STEP
 
 __device__ __noinline__ int exact_signal_wave(const uint8_t *K, uint32_t tj, uint32_t ti, uint32_t n,
                                               float fsize, float thr) {
@@ -358,7 +362,7 @@ __device__ __noinline__ int exact_signal_wave(const uint8_t *K, uint32_t tj, uin
     float sum = 0.0f;
     for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
         const float x = c0 + lane < n ? (float)K[tj + c0 + lane] / fsize : 0.0f;
-        sum = seq_add_64(sum, x);                                                // stat.rs:3
+        sum = seq_add_lanes(sum, x, min(64u, n - c0));                           // stat.rs:3
     }
     const float mean = sum / len;                                                // stat.rs:5
     float sq = 0.0f;
@@ -366,7 +370,7 @@ __device__ __noinline__ int exact_signal_wave(const uint8_t *K, uint32_t tj, uin
         const float x = (float)K[tj + min(c0 + lane, n - 1u)] / fsize;
         const float d = x - mean;
         const float dd = c0 + lane < n ? d * d : 0.0f;
-        sq = seq_add_64(sq, dd);                                                 // stat.rs:12
+        sq = seq_add_lanes(sq, dd, min(64u, n - c0));                            // stat.rs:12
     }
     const float sd = sqrtf(sq / (len - 1.0f));                                   // stat.rs:13
     const float x = (float)K[ti] / fsize;

@@ -48,3 +48,12 @@ print("first 12 entries", entry[order][:12].round(2), "\nlast 12", entry[order][
 # time line: number of resident workgroups every microsecond
 for t in np.arange(0, end.max(), 1.0):
     print(f"t={t:5.1f} resident={int(((entry <= t) & (end > t)).sum())}")
+# phases of the slowest workgroups (shader cycles)
+dur = (st[:, 1:7].astype(np.int64) - st[:, 0:6].astype(np.int64))
+tot = dur.sum(axis=1)
+worst = np.argsort(tot)[-8:]
+print("phase cycles [load, (prefix), counts, z, exact, outputs] of the 8 slowest workgroups:")
+for w in worst:
+    print("  ", dur[w].tolist(), "total", int(tot[w]))
+ex = dur[:, 4]
+print("exact phase: median", int(np.median(ex)), "n>1000:", int((ex > 1000).sum()), "mean of those", int(ex[ex > 1000].mean()) if (ex > 1000).any() else 0)
