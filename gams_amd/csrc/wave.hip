@@ -667,8 +667,8 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
             const uint32_t lo_q = w0 + base >= lag ? 0u : min((uint32_t)W, lag - (w0 + base));  // q >= lo_q
             can = ((1u << hi_q) - 1u) & ~((1u << lo_q) - 1u);
         }
-        // per window three bits: sig (D - R > G), nos (R - D > G), up (n*k > S1)
-        uint32_t sigm = 0, nosm = 0, upm = 0;
+        // per window three bits: sig (D - R > G), nos (R - D > G), dn (n*k < S1: sign bit of di)
+        uint32_t sigm = 0, nosm = 0, dnm = 0;
 #pragma unroll
         for (int q = 0; q < W; ++q) {
             const uint32_t kout = (og[q >> 2] >> (8 * (q & 3))) & 0xFFu;
@@ -682,17 +682,17 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
             const float G = __builtin_fmaf(g1, (float)S1, __builtin_fmaf(g23, Df + Rf, g0));
             push_gt_f32(sigm, diff, G);
             push_neg_gt_f32(nosm, diff, G);
-            push_gt_i32(upm, di, 0);
+            dnm = __builtin_amdgcn_alignbit(dnm, (uint32_t)di, 31);   // (dnm << 1) | sign(di), one VALU
             S1 += kin - kout;
             S2 += __umul24(kin, kin) - __umul24(kout, kout);
         }
         // window q sits at bit W-1-q of the accumulators: flip to bit q
         sigm = __brev(sigm) >> (32 - W);
         nosm = __brev(nosm) >> (32 - W);
-        upm = __brev(upm) >> (32 - W);
+        dnm = __brev(dnm) >> (32 - W);
         uint32_t decided = sigm | nosm;
-        crest = sigm & upm;
-        trough = sigm & ~upm;                    // D > R + G > 0, so di != 0 here
+        crest = sigm & ~dnm;                     // D > R + G > 0, so di != 0 here
+        trough = sigm & dnm;
         // Window i == lag averages windows [0,lag) (stat.rs:30-31) like i == lag+1, not
         // [i-1-lag, i-1): its owner (one thread per ctg) redoes the integer decision with the
         // sums over K[base+qlag+1, base+qlag+1+lag).
