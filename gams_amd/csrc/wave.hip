@@ -398,18 +398,6 @@ __global__ void wave_const_table_kernel(int8_t *const_sig, uint32_t size, uint32
     const_sig[k] = (int8_t)sg;
 }
 
-// acc = 2*acc + (x > y): the comparison lands in VCC and v_addc_co shifts it into the
-// accumulator, 2 VALU per recorded bit (a cndmask/or chain costs 3).  Bits arrive MSB first.
-__device__ __forceinline__ void push_gt_f32(uint32_t &acc, float x, float y) {
-    asm("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(x), "v"(y) : "vcc");
-}
-__device__ __forceinline__ void push_neg_gt_f32(uint32_t &acc, float x, float y) {   // (-x > y), negation free
-    asm("v_cmp_gt_f32_e64 vcc, -%1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(x), "v"(y) : "vcc");
-}
-__device__ __forceinline__ void push_gt_i32(uint32_t &acc, int32_t x, int32_t y) {
-    asm("v_cmp_gt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(x), "v"(y) : "vcc");
-}
-
 // =============================================================================
 // wave_fast_kernel<W,SIZE,STEP,LAG>: the tile algorithm for 8-bit counts (size <= 255),
 // step <= 32 and 32-bit variance math (lag*size <= 65535, lag*size^2 < 2^24), i.e. every
@@ -425,8 +413,8 @@ __device__ __forceinline__ void push_gt_i32(uint32_t &acc, int32_t x, int32_t y)
 //            its first window once (v_dot4 on packed bytes: S1 = sum k, S2 = sum k^2) and
 //            then rolls: S(q+1) = S(q) - K[tW+q] + K[tW+q+lag].  All K traffic is whole
 //            dwords at an odd dword stride between lanes (W/4 in {1,3,5}): conflict-free.
-//            Branch-free integer decision; three bits per window go into carry-chain
-//            accumulators.  Window i == lag (averages [0,lag): stat.rs:30-31) is redone by
+//            Branch-free integer decision; three sign bits per window are shifted into
+//            accumulators with v_alignbit.  Window i == lag (averages [0,lag): stat.rs:30-31) is redone by
 //            its owner.  Windows inside the guard band: const_sig table (homopolymer runs)
 //            or exact_signal_wave.
 //   phase 4  dense rows through LDS (coalesced stores) and/or per-thread peak counts ->
@@ -667,8 +655,11 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
             const uint32_t lo_q = w0 + base >= lag ? 0u : min((uint32_t)W, lag - (w0 + base));  // q >= lo_q
             can = ((1u << hi_q) - 1u) & ~((1u << lo_q) - 1u);
         }
-        // per window three bits: sig (D - R > G), nos (R - D > G), dn (n*k < S1: sign bit of di)
+        // per window three bits: sig (D - R > G), nos (R - D > G), dn (n*k < S1: sign bit of di).
+        // The S1 term of the guard band uses the thread's upper bound S1 + W*size (S1 grows by at
+        // most `size` per window): one conversion per thread instead of one per window.
         uint32_t sigm = 0, nosm = 0, dnm = 0;
+        const float gconst = __builtin_fmaf(g1, (float)(S1 + (uint32_t)W * size), g0);
 #pragma unroll
         for (int q = 0; q < W; ++q) {
             const uint32_t kout = (og[q >> 2] >> (8 * (q & 3))) & 0xFFu;
@@ -679,10 +670,12 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
             const float Df = fabsf((float)di);
             const float Rf = thr_abs * __builtin_amdgcn_sqrtf(cvar * (float)V);
             const float diff = Df - Rf;
-            const float G = __builtin_fmaf(g1, (float)S1, __builtin_fmaf(g23, Df + Rf, g0));
-            push_gt_f32(sigm, diff, G);
-            push_neg_gt_f32(nosm, diff, G);
-            dnm = __builtin_amdgcn_alignbit(dnm, (uint32_t)di, 31);   // (dnm << 1) | sign(di), one VALU
+            const float G = __builtin_fmaf(g23, Df + Rf, gconst);
+            // one bit per test, shifted in MSB first: the sign bits of G - diff (diff > G),
+            // G + diff (diff < -G) and di; (acc << 1) | sign(x) is a single v_alignbit
+            sigm = __builtin_amdgcn_alignbit(sigm, __float_as_uint(G - diff), 31);
+            nosm = __builtin_amdgcn_alignbit(nosm, __float_as_uint(G + diff), 31);
+            dnm = __builtin_amdgcn_alignbit(dnm, (uint32_t)di, 31);
             S1 += kin - kout;
             S2 += __umul24(kin, kin) - __umul24(kout, kout);
         }
@@ -690,6 +683,7 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
         sigm = __brev(sigm) >> (32 - W);
         nosm = __brev(nosm) >> (32 - W);
         dnm = __brev(dnm) >> (32 - W);
+        if (!(g0 < INFINITY)) sigm = nosm = 0;   // non-finite / negative threshold: every window is exact
         uint32_t decided = sigm | nosm;
         crest = sigm & ~dnm;                     // D > R + G > 0, so di != 0 here
         trough = sigm & dnm;
