@@ -467,7 +467,11 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
         constexpr uint32_t NLD = (NCH + 255u) / 256u;
         uint4 v[NLD];
 #pragma unroll
-        for (uint32_t k = 0; k < NLD; ++k) v[k] = src[tid + 256u * k];
+        for (uint32_t k = 0; k + 1u < NLD; ++k) v[k] = src[tid + 256u * k];
+        // the last row is only partly inside the largest tile: lanes past it skip the load
+        // (issued last, so the predicated block delays no other load)
+        v[NLD - 1u] = make_uint4(0, 0, 0, 0);
+        if (tid + 256u * (NLD - 1u) < NCH) v[NLD - 1u] = src[tid + 256u * (NLD - 1u)];
 #pragma unroll
         for (uint32_t k = 0; k < NLD; ++k) BM[tid + 256u * k] = (uint16_t)gc_mask16(v[k]);
     } else
