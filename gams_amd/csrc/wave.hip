@@ -1044,8 +1044,11 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
                 continue;
             }
             // default: W = 12 once that still gives >= 4 tiles per CU, else W = 4 (more, shorter
-            // workgroups: a small genome is launch-latency bound).  W = 20 only on request.
+            // workgroups: a small genome is launch-latency bound).  W = 20 for the baked step-1
+            // kernel (measured 452 vs 503 us on 3.8e8 windows), otherwise only on request.
             const uint64_t tiles = p->total_windows / tw;
+            const bool step1 = q.size == 100 && q.step == 1 && q.lag == 100;   // baked W = 20 fits 64 VGPRs
+            if (pick == 0 && w == 20 && step1 && tiles >= 1024) pick = w;
             if (pick == 0 && w == 12 && tiles >= 1024) pick = w;
             if (pick == 0 && w == 4) pick = w;
         }
@@ -1308,10 +1311,13 @@ int gams_wave_run(gams_gpu_t *h, gams_wave_plan_t *p) {
     a.dense_sig = p->d_dense_sig;
     int rc;
     const bool headline = q.size == 100 && q.step == 10 && q.lag == 100;   // every BASELINE step-10 config
+    const bool step1 = q.size == 100 && q.step == 1 && q.lag == 100;       // BASELINE configs[3] (GRCh38, step 1)
     if (p->fast_w == 20)
-        rc = wave_launch_fast<20, 0, 0, 0>(h, p, a);
+        rc = step1 ? wave_launch_fast<20, 100, 1, 100>(h, p, a) : wave_launch_fast<20, 0, 0, 0>(h, p, a);
     else if (p->fast_w == 12)
-        rc = headline ? wave_launch_fast<12, 100, 10, 100>(h, p, a) : wave_launch_fast<12, 0, 0, 0>(h, p, a);
+        rc = headline ? wave_launch_fast<12, 100, 10, 100>(h, p, a)
+             : step1  ? wave_launch_fast<12, 100, 1, 100>(h, p, a)
+                      : wave_launch_fast<12, 0, 0, 0>(h, p, a);
     else if (p->fast_w == 4)
         rc = headline ? wave_launch_fast<4, 100, 10, 100>(h, p, a) : wave_launch_fast<4, 0, 0, 0>(h, p, a);
     else if (p->k16)
