@@ -2,6 +2,8 @@
 
 #include "common.hpp"
 
+#include <algorithm>
+
 extern "C" {
 
 int gams_gpu_create(int device, gams_gpu_t **out) {
@@ -51,6 +53,10 @@ void gams_gpu_destroy(gams_gpu_t *h) {
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->k0) (void)hipEventDestroy(h->k0);
     if (h->k1) (void)hipEventDestroy(h->k1);
+    for (int k = 0; k < gams_gpu::kStageSlots; ++k) {
+        if (h->stage[k]) (void)hipHostFree(h->stage[k]);
+        if (h->stage_free[k]) (void)hipEventDestroy(h->stage_free[k]);
+    }
     delete h;
 }
 
@@ -141,8 +147,29 @@ int gams_seqset_upload(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, const uint8_
         GAMS_HIP(h, hipStreamSynchronize(h->compute));
         gams_seqset_gcindex_free(s);  // the bytes it indexed are about to change
     }
-    GAMS_HIP(h, hipMemcpyAsync(s->d_seq + s->off[i], seq, s->len[i], hipMemcpyHostToDevice, h->copy));
-    GAMS_HIP(h, hipStreamSynchronize(h->copy));
+    // Pageable host memory -> pinned ring -> HBM: the call returns once the last piece is queued;
+    // the host memcpy of piece k+1 overlaps the DMA of piece k.  Kernels that read the seqset
+    // wait on s->uploaded (gams_seqset_wait_uploads), not the host.
+    for (int k = 0; k < gams_gpu::kStageSlots; ++k) {
+        if (!h->stage[k]) {
+            GAMS_HIP(h, hipHostMalloc(reinterpret_cast<void **>(&h->stage[k]), gams_gpu::kStageBytes, hipHostMallocDefault));
+            GAMS_HIP(h, hipEventCreateWithFlags(&h->stage_free[k], hipEventDisableTiming));
+            GAMS_HIP(h, hipEventRecord(h->stage_free[k], h->copy));
+        }
+    }
+    if (!s->uploaded) GAMS_HIP(h, hipEventCreateWithFlags(&s->uploaded, hipEventDisableTiming));
+    const uint64_t len = s->len[i];
+    for (uint64_t o = 0; o < len; o += gams_gpu::kStageBytes) {
+        const size_t n = (size_t)std::min<uint64_t>(gams_gpu::kStageBytes, len - o);
+        const int k = h->stage_next;
+        h->stage_next = (k + 1) % gams_gpu::kStageSlots;
+        GAMS_HIP(h, hipEventSynchronize(h->stage_free[k]));          // the DMA that used this slot is done
+        std::memcpy(h->stage[k], seq + o, n);
+        GAMS_HIP(h, hipMemcpyAsync(s->d_seq + s->off[i] + o, h->stage[k], n, hipMemcpyHostToDevice, h->copy));
+        GAMS_HIP(h, hipEventRecord(h->stage_free[k], h->copy));
+    }
+    GAMS_HIP(h, hipEventRecord(s->uploaded, h->copy));
+    s->dirty = true;
     return GAMS_OK;
 }
 
@@ -152,9 +179,20 @@ void gams_seqset_destroy(gams_gpu_t *h, gams_seqset_t *s) {
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->compute);
     }
+    if (h) (void)hipStreamSynchronize(h->copy);
     gams_seqset_gcindex_free(s);
+    if (s->uploaded) (void)hipEventDestroy(s->uploaded);
     (void)hipFree(s->d_seq);
     delete s;
 }
 
 }  // extern "C"
+
+int gams_seqset_wait_uploads(gams_gpu_t *h, gams_seqset_t *s) {
+    if (s->dirty) {
+        GAMS_HIP(h, hipStreamWaitEvent(h->compute, s->uploaded, 0));
+        s->dirty = false;
+    }
+    return GAMS_OK;
+}
+

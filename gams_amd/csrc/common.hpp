@@ -18,6 +18,12 @@ struct gams_gpu {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t k0 = nullptr, k1 = nullptr;  // around the kernel of the last query-style call
     bool k_valid = false;
+    // pinned staging ring of the copy stream: the CPU fills slot k+1 while the DMA drains slot k
+    static constexpr int kStageSlots = 2;
+    static constexpr size_t kStageBytes = 16u << 20;
+    uint8_t *stage[kStageSlots] = {nullptr, nullptr};
+    hipEvent_t stage_free[kStageSlots] = {nullptr, nullptr};
+    int stage_next = 0;
     int cus = 0;
     uint64_t hbm = 0;
     char arch[64] = {0};
@@ -46,9 +52,13 @@ struct gams_seqset {
     std::vector<uint64_t> off;      // byte offset of ctg i inside d_seq (256-B aligned)
     uint64_t bytes = 0;             // allocation size (with tail slack for 16-B over-reads)
     uint8_t *d_seq = nullptr;
+    hipEvent_t uploaded = nullptr;    // recorded on the copy stream after the last upload; kernels wait on it
+    bool dirty = false;               // an upload happened since the last wait was queued
     gams_gcindex *gcindex = nullptr;  // built lazily by gams_gpu_sw, dropped by every upload
 };
 
+// make the compute stream wait for every upload queued so far (no host blocking)
+int gams_seqset_wait_uploads(gams_gpu_t *h, gams_seqset_t *s);
 int gams_seqset_gcindex(gams_gpu_t *h, gams_seqset_t *s);
 void gams_seqset_gcindex_free(gams_seqset_t *s);
 

@@ -261,6 +261,8 @@ __global__ __launch_bounds__(256) void range_gc_kernel(const SwArgs a, const int
 // lazily built per seqset; owned by the seqset (freed in gams_seqset_destroy)
 int gams_seqset_gcindex(gams_gpu_t *h, gams_seqset_t *s) {
     if (s->gcindex) return GAMS_OK;
+    int wrc = gams_seqset_wait_uploads(h, s);
+    if (wrc != GAMS_OK) return wrc;
     gams_gcindex *ix = new gams_gcindex();
     ix->n_chunks = s->bytes / 16;
     ix->n_segs = (ix->n_chunks + 4095) / 4096;

@@ -1271,6 +1271,8 @@ int gams_wave_plan_set_tile(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tile_wi
 int gams_wave_run(gams_gpu_t *h, gams_wave_plan_t *p) {
     if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_run: null argument");
     GAMS_HIP(h, hipSetDevice(h->device));
+    int wrc = gams_seqset_wait_uploads(h, p->set);   // stream-side wait: uploads queued on the copy stream
+    if (wrc != GAMS_OK) return wrc;
     const uint32_t slot = (uint32_t)(p->run_idx % kCounterRing);
     if (slot == 0 && p->run_idx > 0)
         GAMS_HIP(h, hipMemsetAsync(p->d_counters, 0, kCounterRing * kSlotWords * sizeof(unsigned long long),
