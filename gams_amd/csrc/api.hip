@@ -30,6 +30,8 @@ int gams_gpu_create(int device, gams_gpu_t **out) {
         return bail(e, "hipStreamCreate(compute)");
     if ((e = hipStreamCreateWithFlags(&h->copy, hipStreamNonBlocking)) != hipSuccess)
         return bail(e, "hipStreamCreate(copy)");
+    if ((e = hipStreamCreateWithFlags(&h->readback, hipStreamNonBlocking)) != hipSuccess)
+        return bail(e, "hipStreamCreate(readback)");
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&h->k0)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -48,6 +50,10 @@ void gams_gpu_destroy(gams_gpu_t *h) {
     if (h->copy) {
         (void)hipStreamSynchronize(h->copy);
         (void)hipStreamDestroy(h->copy);
+    }
+    if (h->readback) {
+        (void)hipStreamSynchronize(h->readback);
+        (void)hipStreamDestroy(h->readback);
     }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -76,6 +82,7 @@ int gams_gpu_sync(gams_gpu_t *h) {
     GAMS_HIP(h, hipSetDevice(h->device));
     GAMS_HIP(h, hipStreamSynchronize(h->copy));
     GAMS_HIP(h, hipStreamSynchronize(h->compute));
+    GAMS_HIP(h, hipStreamSynchronize(h->readback));
     return GAMS_OK;
 }
 

@@ -15,6 +15,7 @@ struct gams_gpu {
     int device = 0;
     hipStream_t compute = nullptr;  // every kernel of the library runs here
     hipStream_t copy = nullptr;     // H2D staging of seq: bytes
+    hipStream_t readback = nullptr; // packing + D2H of a finished run's results (waits on that run only)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t k0 = nullptr, k1 = nullptr;  // around the kernel of the last query-style call
     bool k_valid = false;

@@ -34,6 +34,10 @@ def load():
     L.gams_host_wave.restype = C.c_void_p
     L.gams_host_wave.argtypes = [C.c_void_p, C.c_uint32, sp, sp, ip, ip, C.POINTER(C.c_void_p), C.c_int32,
                                  C.c_int32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_int]
+    L.gams_host_wave_multi.restype = C.c_void_p
+    L.gams_host_wave_multi.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, sp, sp, ip, ip,
+                                       C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_uint32, C.c_float,
+                                       C.c_float, C.c_float, C.c_int, C.c_uint64]
     L.gams_host_sw.restype = C.c_void_p
     L.gams_host_sw.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint32,
                                sp, ip, ip, C.c_int32, C.c_int32, C.c_int32]
@@ -90,6 +94,19 @@ def wave(eng, ctgs, size=100, step=10, lag=100, threshold=3.0, influence=1.0, co
     seqs = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in bufs])
     return _take(load().gams_host_wave(eng.h, n, ids, chrs, st.ctypes.data, en.ctypes.data, seqs, size, step, lag,
                                        threshold, influence, coverage, int(is_signal)))
+
+
+def wave_multi(engines, ctgs, size=100, step=10, lag=100, threshold=3.0, influence=1.0, coverage=0.2,
+               is_signal=False, batch_bytes=1 << 30):
+    """`gams wave` over several handles (one per GPU): LPT-sharded ctgs, one host thread per handle."""
+    n, ids, chrs, st, en = _ctg_arrays(ctgs)
+    bufs = [np.ascontiguousarray(np.frombuffer(c["seq"], np.uint8) if not isinstance(c["seq"], np.ndarray)
+                                 else c["seq"]) for c in ctgs]
+    seqs = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in bufs])
+    hs = (C.c_void_p * len(engines))(*[e.h.value for e in engines])
+    return _take(load().gams_host_wave_multi(hs, len(engines), n, ids, chrs, st.ctypes.data, en.ctypes.data, seqs,
+                                             size, step, lag, threshold, influence, coverage, int(is_signal),
+                                             batch_bytes))
 
 
 def sw(eng, ctg, features, size=100, mx=20, resize=500):

@@ -7,7 +7,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <memory>
 #include <numeric>
+#include <queue>
+#include <thread>
 
 #include <zlib.h>
 
@@ -207,21 +211,40 @@ Merge merge_ints(const std::vector<uint32_t> &w, int32_t chr_start, int32_t size
 
 }  // namespace
 
-std::vector<std::string> wave_proc_ctgs(gams_gpu_t *h, const std::vector<Ctg> &ctgs,
-                                        const std::vector<const uint8_t *> &seqs, const WaveArgs &a) {
-    if (ctgs.size() != seqs.size()) throw Error(GAMS_EINVAL, "wave_proc_ctgs: ctgs/seqs size mismatch");
+namespace {
+
+// One batch of ctgs in flight on one handle: start() queues the uploads (copy stream) and the
+// kernels (compute stream, behind the upload event) and returns; finish() waits, fetches and
+// formats.  Starting batch k+1 before finishing batch k overlaps its upload with k's kernel and
+// k's host-side merge/formatting with k+1's kernel.
+struct WaveJob {
+    gams_gpu_t *h;
+    std::vector<Ctg> ctgs;
+    WaveArgs a;
+    SeqSetGuard sg;
+    PlanGuard pg;
+    WaveJob(gams_gpu_t *h_, std::vector<Ctg> c, const WaveArgs &a_) : h(h_), ctgs(std::move(c)), a(a_), sg{h_}, pg{h_} {}
+    void start(const std::vector<const uint8_t *> &seqs);
+    std::vector<std::string> finish();
+};
+
+void WaveJob::start(const std::vector<const uint8_t *> &seqs) {
     const uint32_t n = (uint32_t)ctgs.size();
-    std::vector<std::string> out(n);
-    if (n == 0) return out;
+    if (n == 0) return;
     std::vector<uint32_t> lens(n);
     for (uint32_t c = 0; c < n; ++c) lens[c] = (uint32_t)(ctgs[c].chr_end - ctgs[c].chr_start + 1);
-    SeqSetGuard sg{h};
     check(h, gams_seqset_create(h, n, lens.data(), &sg.s));
     for (uint32_t c = 0; c < n; ++c) check(h, gams_seqset_upload(h, sg.s, c, seqs[c]));
     gams_wave_params_t prm{a.size, a.step, a.lag, a.threshold, a.influence};
-    PlanGuard pg{h};
     check(h, gams_wave_plan_create(h, sg.s, &prm, a.signal ? GAMS_WAVE_DENSE : GAMS_WAVE_PEAKS, &pg.p));
+    check(h, gams_wave_plan_set_pipelined(h, pg.p, 1));   // finish() waits for this job, not the stream
     check(h, gams_wave_run(h, pg.p));
+}
+
+std::vector<std::string> WaveJob::finish() {
+    const uint32_t n = (uint32_t)ctgs.size();
+    std::vector<std::string> out(n);
+    if (n == 0) return out;
     const float fsize = (float)a.size;
     if (a.signal) {                                                     // wave.rs:158-168
         for (uint32_t c = 0; c < n; ++c) {
@@ -295,8 +318,102 @@ std::vector<std::string> wave_proc_ctgs(gams_gpu_t *h, const std::vector<Ctg> &c
     return out;
 }
 
+}  // namespace
+
+std::vector<std::string> wave_proc_ctgs(gams_gpu_t *h, const std::vector<Ctg> &ctgs,
+                                        const std::vector<const uint8_t *> &seqs, const WaveArgs &a) {
+    if (ctgs.size() != seqs.size()) throw Error(GAMS_EINVAL, "wave_proc_ctgs: ctgs/seqs size mismatch");
+    WaveJob job(h, ctgs, a);
+    job.start(seqs);
+    return job.finish();
+}
+
 std::string wave_proc_ctg(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq, const WaveArgs &a) {
     return wave_proc_ctgs(h, {ctg}, {seq}, a)[0];
+}
+
+std::vector<uint32_t> lpt_assign(const std::vector<uint64_t> &weights, uint32_t n_owners) {
+    std::vector<size_t> order(weights.size());
+    std::iota(order.begin(), order.end(), (size_t)0);
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weights[a] > weights[b]; });
+    using Load = std::pair<uint64_t, uint32_t>;  // (load, owner): smallest load first, then smallest owner
+    std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+    for (uint32_t o = 0; o < n_owners; ++o) heap.push({0, o});
+    std::vector<uint32_t> owner(weights.size(), 0);
+    for (size_t i : order) {
+        Load l = heap.top();
+        heap.pop();
+        owner[i] = l.second;
+        heap.push({l.first + weights[i], l.second});
+    }
+    return owner;
+}
+
+std::vector<std::string> wave_proc_ctgs_multi(const std::vector<gams_gpu_t *> &handles, const std::vector<Ctg> &ctgs,
+                                              const std::vector<const uint8_t *> &seqs, const WaveArgs &a,
+                                              uint64_t batch_bytes) {
+    if (handles.empty()) throw Error(GAMS_EINVAL, "wave_proc_ctgs_multi: no handles");
+    if (ctgs.size() != seqs.size()) throw Error(GAMS_EINVAL, "wave_proc_ctgs_multi: ctgs/seqs size mismatch");
+    const uint32_t G = (uint32_t)handles.size();
+    std::vector<uint64_t> weight(ctgs.size());
+    for (size_t c = 0; c < ctgs.size(); ++c) {
+        const int64_t n = gams_window_count((int64_t)ctgs[c].chr_end - ctgs[c].chr_start + 1, a.size, a.step);
+        weight[c] = n > 0 ? (uint64_t)n : 0;
+    }
+    const std::vector<uint32_t> owner = lpt_assign(weight, G);
+    std::vector<std::string> out(ctgs.size());
+    std::vector<std::exception_ptr> errs(G);
+    auto work = [&](uint32_t g) {
+        try {
+            // this device's ctgs, in ctg order, cut into batches of <= batch_bytes bases
+            std::vector<size_t> mine;
+            for (size_t c = 0; c < ctgs.size(); ++c)
+                if (owner[c] == g) mine.push_back(c);
+            // cut this device's share into batches, keep two jobs in flight
+            std::vector<std::pair<size_t, size_t>> batches;   // [b, e) into `mine`
+            for (size_t b = 0; b < mine.size();) {
+                uint64_t bytes = 0;
+                size_t e = b;
+                while (e < mine.size()) {
+                    const uint64_t len = (uint64_t)(ctgs[mine[e]].chr_end - ctgs[mine[e]].chr_start + 1);
+                    if (e > b && bytes + len > batch_bytes) break;
+                    bytes += len;
+                    ++e;
+                }
+                batches.emplace_back(b, e);
+                b = e;
+            }
+            auto make_job = [&](size_t k) {
+                std::vector<Ctg> bc;
+                std::vector<const uint8_t *> bs;
+                for (size_t i = batches[k].first; i < batches[k].second; ++i) {
+                    bc.push_back(ctgs[mine[i]]);
+                    bs.push_back(seqs[mine[i]]);
+                }
+                std::unique_ptr<WaveJob> job(new WaveJob(handles[g], std::move(bc), a));
+                job->start(bs);
+                return job;
+            };
+            std::unique_ptr<WaveJob> cur, next;
+            if (!batches.empty()) cur = make_job(0);
+            for (size_t k = 0; k < batches.size(); ++k) {
+                if (k + 1 < batches.size()) next = make_job(k + 1);     // queued behind batch k on the device
+                std::vector<std::string> rows = cur->finish();
+                for (size_t i = batches[k].first; i < batches[k].second; ++i)
+                    out[mine[i]] = std::move(rows[i - batches[k].first]);
+                cur = std::move(next);
+            }
+        } catch (...) {
+            errs[g] = std::current_exception();
+        }
+    };
+    std::vector<std::thread> threads;
+    for (uint32_t g = 1; g < G; ++g) threads.emplace_back(work, g);
+    work(0);
+    for (auto &t : threads) t.join();
+    for (auto &e : errs)
+        if (e) std::rethrow_exception(e);
+    return out;
 }
 
 // ---------------------------------------------------------------------------

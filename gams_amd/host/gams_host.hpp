@@ -72,6 +72,15 @@ public:
 std::vector<std::string> wave_proc_ctgs(gams_gpu_t *h, const std::vector<Ctg> &ctgs,
                                         const std::vector<const uint8_t *> &seqs, const WaveArgs &a);
 std::string wave_proc_ctg(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq, const WaveArgs &a);
+// The multi-GPU form: ctgs are split over the handles by longest-
+// processing-time-first on their window counts, one host thread per handle, each thread walks
+// its share in batches of at most `batch_bytes` bases (upload of batch k+1 overlaps the kernel
+// of batch k).  No device talks to another; the per-ctg Strings come back in ctg order.
+std::vector<std::string> wave_proc_ctgs_multi(const std::vector<gams_gpu_t *> &handles, const std::vector<Ctg> &ctgs,
+                                              const std::vector<const uint8_t *> &seqs, const WaveArgs &a,
+                                              uint64_t batch_bytes = 1ull << 30);
+// longest-processing-time-first assignment (weights -> owner per item); ties by index
+std::vector<uint32_t> lpt_assign(const std::vector<uint64_t> &weights, uint32_t n_owners);
 
 // sw.rs:108-194
 std::string sw_proc_ctg(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq, const std::vector<Feature> &features,

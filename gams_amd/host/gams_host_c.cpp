@@ -82,6 +82,28 @@ char *gams_host_wave(gams_gpu_t *h, uint32_t n, const char *const *ids, const ch
     });
 }
 
+// the same over several handles (one per device; tests pass two handles of one device)
+char *gams_host_wave_multi(gams_gpu_t *const *handles, uint32_t n_handles, uint32_t n, const char *const *ids,
+                           const char *const *chrs, const int32_t *starts, const int32_t *ends,
+                           const uint8_t *const *seqs, int32_t size, int32_t step, uint32_t lag, float threshold,
+                           float influence, float coverage, int is_signal, uint64_t batch_bytes) {
+    return guarded([&] {
+        gams::WaveArgs a;
+        a.size = size;
+        a.step = step;
+        a.lag = lag;
+        a.threshold = threshold;
+        a.influence = influence;
+        a.coverage = coverage;
+        a.signal = is_signal != 0;
+        std::vector<gams_gpu_t *> hs(handles, handles + n_handles);
+        std::vector<const uint8_t *> sp(seqs, seqs + n);
+        std::string out;
+        for (auto &s : gams::wave_proc_ctgs_multi(hs, make_ctgs(n, ids, chrs, starts, ends), sp, a, batch_bytes)) out += s;
+        return out;
+    });
+}
+
 // sw.rs:108-194 for one ctg
 char *gams_host_sw(gams_gpu_t *h, const char *ctg_id, const char *chr, int32_t chr_start, int32_t chr_end,
                    const uint8_t *seq, uint32_t nf, const char *const *feature_ids, const int32_t *fs,

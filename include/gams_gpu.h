@@ -108,6 +108,11 @@ uint64_t gams_wave_total_windows(const gams_wave_plan_t *p);
 uint32_t gams_wave_ctg_windows(const gams_wave_plan_t *p, uint32_t i);
 /* One pass: queue the kernels on the compute stream (asynchronous). */
 int gams_wave_run(gams_gpu_t *h, gams_wave_plan_t *p);
+/* Pipelined plans record an event behind every run, and gams_wave_peaks / gams_wave_dense wait
+ * for that run only (so a host can keep several plans in flight on one handle: upload of batch
+ * k+1 and its kernel overlap the readback and formatting of batch k).  Off by default: the
+ * event costs a marker packet between back-to-back launches. */
+int gams_wave_plan_set_pipelined(gams_gpu_t *h, gams_wave_plan_t *p, int enable);
 /* Wait for the last run and fetch its compacted peaks, ordered by (ctg, window).
  * *peaks points into plan-owned host memory, valid until the next run. */
 int gams_wave_peaks(gams_gpu_t *h, gams_wave_plan_t *p,

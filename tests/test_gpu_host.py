@@ -321,3 +321,20 @@ def test_command_peak(eng, s288c):
     # a peak range that leaves its ctg (fixture ranges on the piece-100000 layout) is the reference's panic
     with pytest.raises(host.HostError):
         host.peak(eng, all_ctgs(s288c), lines)
+
+
+# ---- multi-device host path, exercised with several handles on one GPU --------
+def test_wave_multi_handles_equals_single(eng, s288c):
+    from gams_amd import synth
+
+    ctgs = all_ctgs(s288c, piece=30000) + synth.genome_ctgs([2_000_000, 700_000], 250000, first_chr_index=90)
+    single = host.wave(eng, ctgs)
+    e2, e3 = engine.Engine(0), engine.Engine(0)
+    try:
+        for engines, batch in (([eng, e2], 1 << 30), ([eng, e2, e3], 400_000), ([eng], 100_000)):
+            assert host.wave_multi(engines, ctgs, batch_bytes=batch) == single
+        assert host.wave_multi([eng, e2], ctgs, is_signal=True, size=50, step=7, lag=33, threshold=2.5) == \
+            host.wave(eng, ctgs, is_signal=True, size=50, step=7, lag=33, threshold=2.5)
+    finally:
+        e2.close()
+        e3.close()
