@@ -208,6 +208,18 @@ def main():
                 "sample": f"first {used} ctgs of the same workload ({done} windows), oracle/gams_oracle.c "
                           f"single thread; host has {os.cpu_count()} cpus",
             }
+            # the reference's --parallel T model (one ctg per worker thread, wave.rs:288-299), for context
+            from concurrent.futures import ThreadPoolExecutor
+            from oracle import oracle as ora
+
+            T = min(16, os.cpu_count() or 1, len(ctgs))
+            t0p = time.perf_counter()
+            with ThreadPoolExecutor(T) as ex:
+                sizes = list(ex.map(lambda c: ora.wave_windows(c["seq"], prm["size"], prm["step"], prm["lag"],
+                                                               prm["threshold"], prm["influence"])[0].size, ctgs))
+            out["cpu_baseline_parallel"] = {"value": sum(sizes) / (time.perf_counter() - t0p), "unit": "windows/s",
+                                            "cores": T, "kind": "port",
+                                            "sample": f"all {len(ctgs)} ctgs, one ctg per worker thread"}
             out["parity_vs_oracle"] = ok
     if rank == 0 and world == 1 and not args.no_extra and args.workload == "S288c" and args.scale == 1.0:
         # The 12 Mb workload lives in L2/MALL and one launch lasts microseconds.  Also measure a
