@@ -56,6 +56,8 @@ def load():
     L.gams_host_decode_gz.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.gams_host_encode_gz.restype = C.c_void_p
     L.gams_host_encode_gz.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.gams_host_loader_records.restype = C.c_void_p
+    L.gams_host_loader_records.argtypes = [C.c_void_p, C.c_uint32, sp, sp, ip, ip, C.c_char_p, C.c_char_p]
     L.gams_host_peak.restype = C.c_void_p
     L.gams_host_peak.argtypes = [C.c_void_p, C.c_uint32, sp, sp, ip, ip, C.POINTER(C.c_void_p), C.c_char_p]
     L.gams_host_gen.restype = C.c_void_p
@@ -184,6 +186,14 @@ def encode_gz(data):
     out = C.string_at(p, n.value)
     load().gams_host_free(p)
     return out
+
+
+def loader_records(eng, ctgs, lines, tag=None):
+    """(key, json) of the rg: (tag None) or feature: records `gams rg` / `gams feature` would SET."""
+    n, ids, chrs, st, en = _ctg_arrays(ctgs)
+    out = _take(load().gams_host_loader_records(eng.h, n, ids, chrs, st.ctypes.data, en.ctypes.data,
+                                                "\n".join(lines).encode(), tag.encode() if tag is not None else None))
+    return [tuple(r.split("\t", 1)) for r in out.splitlines()]
 
 
 def peak(eng, ctgs, lines):

@@ -723,6 +723,43 @@ std::vector<Peak> peak_records(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq
     return out;
 }
 
+namespace {
+std::string json_escape(const std::string &v) {
+    std::string o;
+    for (char c : v) {
+        if (c == '"' || c == '\\') o += '\\';
+        o += c;
+    }
+    return o;
+}
+}  // namespace
+
+std::vector<Record> rg_records(Locator &loc, const std::vector<std::string> &lines) {
+    std::vector<Record> out;
+    for (auto &kv : read_range(loc, lines)) {                           // BTreeMap order = ctg id order
+        int32_t serial = 0;
+        for (const Range &r : kv.second) {
+            const std::string id = "rg:" + kv.first + ":" + std::to_string(++serial);   // rg.rs:64-66
+            out.push_back({id, "{\"id\":\"" + json_escape(id) + "\",\"range\":\"" + json_escape(r.to_string()) + "\"}"});
+        }
+    }
+    return out;
+}
+
+std::vector<Record> feature_records(Locator &loc, const std::vector<std::string> &lines, const std::string &tag) {
+    std::vector<Record> out;
+    for (auto &kv : read_range(loc, lines)) {
+        int32_t serial = 0;
+        for (const Range &r : kv.second) {
+            const std::string id = "feature:" + kv.first + ":" + std::to_string(++serial);   // feature.rs:81-83
+            out.push_back({id, "{\"id\":\"" + json_escape(id) + "\",\"range\":\"" + json_escape(r.to_string()) +
+                                   "\",\"length\":" + std::to_string(r.end - r.start + 1) + ",\"tag\":\"" +
+                                   json_escape(tag) + "\"}"});                               // feature.rs:85-92
+        }
+    }
+    return out;
+}
+
 std::string decode_gz(const uint8_t *bytes, size_t n) {
     z_stream zs{};
     if (inflateInit2(&zs, 15 + 16) != Z_OK) throw Error(GAMS_EINVAL, "decode_gz: inflateInit2 failed");

@@ -140,6 +140,15 @@ std::map<std::string, std::vector<std::pair<Range, std::string>>> read_peak(Loca
 std::vector<Peak> peak_records(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq,
                                const std::vector<std::pair<Range, std::string>> &peaks);
 
+// src/cmd_gams/rg.rs:41-77 / feature.rs:47-95: the records the loaders SET, as (key, JSON) pairs in
+// the reference's order (ctg id order, then file order), serials from 1 per ctg (a fresh cnt:).
+// JSON text as serde_json writes the structs of src/libs/data.rs:16-28 (field order, no spaces).
+struct Record {
+    std::string key, json;
+};
+std::vector<Record> rg_records(Locator &loc, const std::vector<std::string> &lines);
+std::vector<Record> feature_records(Locator &loc, const std::vector<std::string> &lines, const std::string &tag);
+
 // gen.rs:81-157 for one chromosome: ambiguous-base scan (device), fill, excise, --piece split;
 // ctg ids "ctg:{chr}:{serial}" with serial from 1 (gen.rs:133-134).  `seq` is the whole chromosome.
 struct GenArgs {            // defaults of src/cmd_gams/gen.rs:26-49

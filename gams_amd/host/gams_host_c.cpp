@@ -194,6 +194,20 @@ char *gams_host_peak(gams_gpu_t *h, uint32_t n, const char *const *ids, const ch
     });
 }
 
+// rg.rs:41-77 / feature.rs:47-95: rows "key\tjson" of the records the loaders SET (tag == NULL: rg)
+char *gams_host_loader_records(gams_gpu_t *h, uint32_t n, const char *const *ids, const char *const *chrs,
+                               const int32_t *starts, const int32_t *ends, const char *lines, const char *tag) {
+    return guarded([&] {
+        gams::Locator loc(h, make_ctgs(n, ids, chrs, starts, ends));
+        std::vector<std::string> first_cols;
+        for (const std::string &ln : split_lines(lines)) first_cols.push_back(ln.substr(0, ln.find('\t')));
+        std::string out;
+        for (const gams::Record &r : tag ? gams::feature_records(loc, first_cols, tag) : gams::rg_records(loc, first_cols))
+            out += r.key + "\t" + r.json + "\n";
+        return out;
+    });
+}
+
 // gzip framing of seq: values (redis.rs:149-161); *out_len receives the length
 char *gams_host_decode_gz(const uint8_t *bytes, uint64_t n, uint64_t *out_len) {
     return guarded([&] {

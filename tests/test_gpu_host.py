@@ -338,3 +338,22 @@ def test_wave_multi_handles_equals_single(eng, s288c):
     finally:
         e2.close()
         e3.close()
+
+
+def test_command_rg_and_feature_records(eng, s288c):
+    """tests/cli.rs:235-253, 285-304: 69 records each; ids, serials and JSON as the loaders SET them."""
+    import json
+
+    ctgs = all_ctgs(s288c)
+    lines = helpers.read_lines("spo11_hot.rg")
+    rg = host.loader_records(eng, ctgs, lines)
+    ft = host.loader_records(eng, ctgs, lines, tag="spo11")
+    assert len(rg) == 69 and len(ft) == 69
+    assert rg[0][0] == "rg:ctg:I:1:1" and ft[0][0] == "feature:ctg:I:1:1"
+    assert "feature:ctg:I:2:32" in [k for k, _ in ft]                  # the id tests/cli.rs:325 greps for
+    for (k, js), (_, rng) in zip(ft, host.read_range(eng, ctgs, lines)):
+        rec = json.loads(js)
+        chr_id, s, e = helpers.parse_range(rng)
+        assert rec == {"id": k, "range": rng, "length": e - s + 1, "tag": "spo11"}
+        assert list(rec) == ["id", "range", "length", "tag"]           # serde field order (data.rs:16-22)
+    assert json.loads(rg[5][1]) == {"id": rg[5][0], "range": host.read_range(eng, ctgs, lines)[5][1]}
