@@ -152,6 +152,14 @@ def main():
 
     peaks = plan.peaks()
     n_exact = plan.exact_count()
+    # beside `value`: the same pass with the compacted peaks packed and copied to the host every step
+    rb_steps = max(1, min(args.steps, 50))
+    eng.sync()
+    t0r = time.perf_counter()
+    for _ in range(rb_steps):
+        plan.run()
+        plan.peaks()
+    readback_wps = n_windows * rb_steps / (time.perf_counter() - t0r)
 
     out = None
     if rank == 0:
@@ -178,6 +186,7 @@ def main():
                 "windows_per_gpu_per_step": int(n_windows),
                 "peaks_per_step": int(peaks.size),
                 "exact_path_windows": int(n_exact),
+                "windows_per_s_with_host_readback": readback_wps,
                 "device": arch,
                 "parallelism": f"ctg-sharded x{world}, no collective",
             },

@@ -16,39 +16,79 @@
 // stores them (src/libs/redis.rs:245-248, 291-294); queries are passed the way
 // the reference passes them: (rg.start, rg.end), i.e. the end is exclusive.
 // One lane per query; 16 B/query of traffic plus the probed table lines.
+//
+// Random queries make a plain binary search fetch ~log2(n) scattered cache lines per sorted
+// array (measured: 2.8 G queries/s, the L2 line rate).  Every sorted array therefore carries a
+// bucket directory: dir[b] = rank of the first key >= key0 + (b << shift), with about one
+// bucket per key, so a lower bound is one directory line plus a search inside dir[b]..dir[b+1]
+// (typically 0-2 keys, one line).  Skewed keys only lengthen that inner search; the answer is
+// the same lower bound either way.
 
 #include "common.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <numeric>
+#include <thread>
+
+// bucket directory of one sorted key array of one group (32-bit keys, order-preserving bias applied)
+struct KeyDir {
+    uint32_t key0;    // smallest key of the group
+    uint32_t shift;   // bucket b holds keys in [key0 + (b << shift), key0 + ((b+1) << shift))
+    uint32_t nb;      // buckets; nb <= n, dir has nb+1 entries at dir[off + g]
+    uint32_t pad;
+};
+
+// everything a query needs to know about its group, one 48-B record (one or two lines)
+struct IndexGroup {
+    uint64_t off;     // first interval of the group
+    uint32_t n;       // intervals in the group
+    uint32_t maxlen;  // max(stop - start), Lapper::max_len
+    KeyDir start, stop;
+};
+
+struct SpanGroup {
+    uint64_t off;
+    uint32_t n;
+    uint32_t pad;
+    KeyDir lo;
+};
 
 struct gams_index {
     uint32_t n_groups = 0;
     uint64_t m = 0;
-    uint64_t *d_off = nullptr;       // n_groups+1
-    uint32_t *d_starts = nullptr;    // per group, ascending (for count)
+    IndexGroup *d_groups = nullptr;
     uint32_t *d_stops = nullptr;     // per group, ascending, sorted independently (for count)
-    uint32_t *d_lstart = nullptr;    // per group, (start,stop)-sorted pairs (for locate)
+    uint32_t *d_lstart = nullptr;    // per group, (start,stop)-sorted pairs; the starts alone are ascending
     uint32_t *d_lstop = nullptr;
     uint64_t *d_lorig = nullptr;     // caller's index of each sorted pair
-    uint32_t *d_maxlen = nullptr;    // per group: max(stop - start)
+    uint32_t *d_dir_start = nullptr; // m + n_groups entries: group g's directory begins at off[g] + g
+    uint32_t *d_dir_stop = nullptr;
 };
 
 struct gams_spans {
     uint32_t n_groups = 0;
     uint64_t m = 0;
-    uint64_t *d_off = nullptr;
+    SpanGroup *d_groups = nullptr;
     int32_t *d_lo = nullptr, *d_hi = nullptr;
     uint64_t *d_cum = nullptr;       // covered bases in the group's spans before span i
+    uint32_t *d_dir_lo = nullptr;
 };
 
 namespace {
 
-// first index in [lo,hi) whose value is >= key (number of elements < key, offset by lo)
-__device__ __forceinline__ uint64_t lower_bound_u32(const uint32_t *a, uint64_t lo, uint64_t hi, uint64_t key) {
+// Number of keys < key among the group's n ascending keys a[0..n) (rank of the lower bound).
+// BIAS = 0x80000000 compares int32 keys stored as they are (x ^ BIAS is order preserving).
+template <uint32_t BIAS>
+__device__ __forceinline__ uint32_t dir_lower_bound(const uint32_t *a, const uint32_t *dir, uint32_t n,
+                                                    const KeyDir d, uint64_t key) {
+    if (n == 0 || key <= (uint64_t)d.key0) return 0;
+    const uint64_t b = (key - d.key0) >> d.shift;
+    if (b >= d.nb) return n;                       // beyond the last bucket: beyond the largest key
+    uint32_t lo = dir[b], hi = dir[b + 1];
     while (lo < hi) {
-        const uint64_t mid = lo + ((hi - lo) >> 1);
-        if ((uint64_t)a[mid] < key)
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((uint64_t)(a[mid] ^ BIAS) < key)
             lo = mid + 1;
         else
             hi = mid;
@@ -56,8 +96,9 @@ __device__ __forceinline__ uint64_t lower_bound_u32(const uint32_t *a, uint64_t 
     return lo;
 }
 
-__global__ __launch_bounds__(256) void interval_count_kernel(const uint64_t *off, const uint32_t *starts,
-                                                             const uint32_t *stops, uint32_t n_groups,
+__global__ __launch_bounds__(256) void interval_count_kernel(const IndexGroup *groups, const uint32_t *starts,
+                                                             const uint32_t *stops, const uint32_t *dir_start,
+                                                             const uint32_t *dir_stop, uint32_t n_groups,
                                                              const uint32_t *group, const uint32_t *qs,
                                                              const uint32_t *qe, uint64_t nq, int32_t *out) {
     const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -67,16 +108,16 @@ __global__ __launch_bounds__(256) void interval_count_kernel(const uint64_t *off
         out[q] = 0;
         return;
     }
-    const uint64_t lo = off[g], hi = off[g + 1];
+    const IndexGroup G = groups[g];
     // Lapper::count: first = bsearch_seq(start + 1, stops); last = bsearch_seq(stop, starts)
-    const uint64_t first = lower_bound_u32(stops, lo, hi, (uint64_t)qs[q] + 1u) - lo;
-    const uint64_t last = lower_bound_u32(starts, lo, hi, (uint64_t)qe[q]) - lo;
+    const uint32_t first = dir_lower_bound<0u>(stops + G.off, dir_stop + G.off + g, G.n, G.stop, (uint64_t)qs[q] + 1u);
+    const uint32_t last = dir_lower_bound<0u>(starts + G.off, dir_start + G.off + g, G.n, G.start, (uint64_t)qe[q]);
     out[q] = (int32_t)((int64_t)last - (int64_t)first);
 }
 
-__global__ __launch_bounds__(256) void interval_locate_kernel(const uint64_t *off, const uint32_t *lstart,
+__global__ __launch_bounds__(256) void interval_locate_kernel(const IndexGroup *groups, const uint32_t *lstart,
                                                               const uint32_t *lstop, const uint64_t *lorig,
-                                                              const uint32_t *maxlen, uint32_t n_groups,
+                                                              const uint32_t *dir_start, uint32_t n_groups,
                                                               const uint32_t *group, const uint32_t *qs,
                                                               const uint32_t *qe, uint64_t nq, int64_t *out) {
     const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -84,12 +125,13 @@ __global__ __launch_bounds__(256) void interval_locate_kernel(const uint64_t *of
     const uint32_t g = group[q];
     int64_t hit = -1;
     if (g < n_groups) {
-        const uint64_t lo = off[g], hi = off[g + 1];
+        const IndexGroup G = groups[g];
         const uint32_t s = qs[q], e = qe[q];
-        const uint32_t ml = maxlen[g];
-        const uint32_t from = s > ml ? s - ml : 0u;  // checked_sub(max_len).unwrap_or(0)
+        const uint32_t from = s > G.maxlen ? s - G.maxlen : 0u;  // checked_sub(max_len).unwrap_or(0)
         // Lapper::lower_bound: first interval whose start >= from
-        for (uint64_t i = lower_bound_u32(lstart, lo, hi, from); i < hi; ++i) {
+        const uint64_t hi = G.off + G.n;
+        for (uint64_t i = G.off + dir_lower_bound<0u>(lstart + G.off, dir_start + G.off + g, G.n, G.start, from);
+             i < hi; ++i) {
             const uint32_t is = lstart[i];
             if (is < e && lstop[i] > s) {  // Interval::overlap
                 hit = (int64_t)lorig[i];
@@ -101,33 +143,25 @@ __global__ __launch_bounds__(256) void interval_locate_kernel(const uint64_t *of
     out[q] = hit;
 }
 
-// number of spans in [lo,hi) with span_lo <= x
-__device__ __forceinline__ uint64_t upper_bound_i32(const int32_t *a, uint64_t lo, uint64_t hi, int32_t x) {
-    while (lo < hi) {
-        const uint64_t mid = lo + ((hi - lo) >> 1);
-        if (a[mid] <= x)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    return lo;
-}
-
 // covered positions <= x inside the group's spans
 __device__ __forceinline__ uint64_t covered_upto(const int32_t *slo, const int32_t *shi, const uint64_t *cum,
-                                                 uint64_t lo, uint64_t hi, int32_t x) {
-    const uint64_t i = upper_bound_i32(slo, lo, hi, x);
-    if (i == lo) return 0;
-    const int32_t top = shi[i - 1] < x ? shi[i - 1] : x;
-    return cum[i - 1] + (uint64_t)((int64_t)top - slo[i - 1] + 1);
+                                                 const uint32_t *dir, const SpanGroup &G, uint32_t g, int32_t x) {
+    // spans with lo <= x = keys < x+1 in biased order
+    const uint32_t i = dir_lower_bound<0x80000000u>(reinterpret_cast<const uint32_t *>(slo) + G.off,
+                                                    dir + G.off + g, G.n, G.lo,
+                                                    (uint64_t)((uint32_t)x ^ 0x80000000u) + 1u);
+    if (i == 0) return 0;
+    const uint64_t j = G.off + i - 1;
+    const int32_t top = shi[j] < x ? shi[j] : x;
+    return cum[j] + (uint64_t)((int64_t)top - slo[j] + 1);
 }
 
-__global__ __launch_bounds__(256) void span_cover_kernel(const uint64_t *off, const int32_t *slo,
+__global__ __launch_bounds__(256) void span_cover_kernel(const SpanGroup *groups, const int32_t *slo,
                                                          const int32_t *shi, const uint64_t *cum,
-                                                         uint32_t n_groups, const uint32_t *group,
-                                                         const int32_t *clip_lo, const int32_t *clip_hi,
-                                                         const int32_t *qs, const int32_t *qe, uint64_t nq,
-                                                         float *out) {
+                                                         const uint32_t *dir, uint32_t n_groups,
+                                                         const uint32_t *group, const int32_t *clip_lo,
+                                                         const int32_t *clip_hi, const int32_t *qs,
+                                                         const int32_t *qe, uint64_t nq, float *out) {
     const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const uint32_t g = group[q];
@@ -138,15 +172,53 @@ __global__ __launch_bounds__(256) void span_cover_kernel(const uint64_t *off, co
         const int32_t H = e < clip_hi[q] ? e : clip_hi[q];
         uint64_t card = 0;
         if (H >= L) {
-            const uint64_t lo = off[g], hi = off[g + 1];
-            const uint64_t upto_h = covered_upto(slo, shi, cum, lo, hi, H);
-            const uint64_t upto_l = L > INT32_MIN ? covered_upto(slo, shi, cum, lo, hi, L - 1) : 0;
+            const SpanGroup G = groups[g];
+            const uint64_t upto_h = covered_upto(slo, shi, cum, dir, G, g, H);
+            const uint64_t upto_l = L > INT32_MIN ? covered_upto(slo, shi, cum, dir, G, g, L - 1) : 0;
             card = upto_h - upto_l;
         }
         const int32_t total = (int32_t)((int64_t)e - s + 1);
         prop = (float)(int32_t)card / (float)total;  // cardinality() as f32 / cardinality() as f32
     }
     out[q] = prop;
+}
+
+// Host side of the directory: keys[0..n) ascending (already biased); dir gets nb+1 <= n+1 entries.
+KeyDir build_dir(const uint32_t *keys, uint32_t n, uint32_t *dir) {
+    KeyDir d{0u, 0u, 0u, 0u};
+    if (n == 0) {
+        dir[0] = 0;
+        return d;
+    }
+    d.key0 = keys[0];
+    const uint32_t range = keys[n - 1] - keys[0];
+    while ((range >> d.shift) >= n) ++d.shift;     // (range >> shift) + 1 <= n buckets
+    d.nb = (range >> d.shift) + 1u;
+    uint32_t i = 0;
+    for (uint32_t b = 0; b < d.nb; ++b) {
+        const uint64_t edge = (uint64_t)d.key0 + ((uint64_t)b << d.shift);
+        while (i < n && (uint64_t)keys[i] < edge) ++i;
+        dir[b] = i;
+    }
+    dir[d.nb] = n;
+    return d;
+}
+
+// run fn(g) for every group on up to 16 host threads (the per-group sorts dominate index creation)
+template <typename F>
+void for_groups(uint32_t n_groups, F fn) {
+    const unsigned T = std::max(1u, std::min({16u, std::thread::hardware_concurrency(), n_groups}));
+    if (T <= 1) {
+        for (uint32_t g = 0; g < n_groups; ++g) fn(g);
+        return;
+    }
+    std::atomic<uint32_t> next{0};
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < T; ++t)
+        pool.emplace_back([&] {
+            for (uint32_t g = next.fetch_add(1); g < n_groups; g = next.fetch_add(1)) fn(g);
+        });
+    for (auto &th : pool) th.join();
 }
 
 template <typename T>
@@ -184,14 +256,18 @@ int gams_index_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
     if (m && (!starts || !stops)) return gams_fail(h, GAMS_EINVAL, "index_create: null interval arrays");
     for (uint32_t g = 0; g < n_groups; ++g)
         if (group_off[g] > group_off[g + 1]) return gams_fail(h, GAMS_EINVAL, "index_create: group_off not ascending");
+    for (uint32_t g = 0; g < n_groups; ++g)
+        if (group_off[g + 1] - group_off[g] > 0xfffffff0ull)
+            return gams_fail(h, GAMS_EUNSUPPORTED, "index_create: a group holds more than 2^32-16 intervals");
     GAMS_HIP(h, hipSetDevice(h->device));
-    // Lapper::new: intervals.sort() by (start, stop); starts and stops also sorted on their own
-    std::vector<uint32_t> ss(starts, starts + m), tt(stops, stops + m), ls(m), lt(m), maxlen(n_groups, 0);
+    // Lapper::new: intervals.sort() by (start, stop); stops also sorted on their own
+    std::vector<uint32_t> tt(stops, stops + m), ls(m), lt(m);
+    std::vector<uint32_t> dir_s(m + n_groups + 1), dir_t(m + n_groups + 1);
     std::vector<uint64_t> perm(m);
+    std::vector<IndexGroup> groups(std::max<uint32_t>(n_groups, 1));
     std::iota(perm.begin(), perm.end(), 0ull);
-    for (uint32_t g = 0; g < n_groups; ++g) {
+    for_groups(n_groups, [&](uint32_t g) {
         const uint64_t lo = group_off[g], hi = group_off[g + 1];
-        std::sort(ss.begin() + lo, ss.begin() + hi);
         std::sort(tt.begin() + lo, tt.begin() + hi);
         std::stable_sort(perm.begin() + lo, perm.begin() + hi, [&](uint64_t a, uint64_t b) {
             return starts[a] != starts[b] ? starts[a] < starts[b] : stops[a] < stops[b];
@@ -202,18 +278,23 @@ int gams_index_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
             lt[i] = stops[perm[i]];
             if (lt[i] > ls[i]) ml = std::max(ml, lt[i] - ls[i]);
         }
-        maxlen[g] = ml;
-    }
+        IndexGroup &G = groups[g];
+        G.off = lo;
+        G.n = (uint32_t)(hi - lo);
+        G.maxlen = ml;
+        G.start = build_dir(ls.data() + lo, G.n, dir_s.data() + lo + g);
+        G.stop = build_dir(tt.data() + lo, G.n, dir_t.data() + lo + g);
+    });
     gams_index_t *ix = new gams_index_t();
     ix->n_groups = n_groups;
     ix->m = m;
-    hipError_t e = to_device(&ix->d_off, group_off, (size_t)n_groups + 1);
-    if (e == hipSuccess) e = to_device(&ix->d_starts, ss.data(), m);
+    hipError_t e = to_device(&ix->d_groups, groups.data(), groups.size());
     if (e == hipSuccess) e = to_device(&ix->d_stops, tt.data(), m);
     if (e == hipSuccess) e = to_device(&ix->d_lstart, ls.data(), m);
     if (e == hipSuccess) e = to_device(&ix->d_lstop, lt.data(), m);
     if (e == hipSuccess) e = to_device(&ix->d_lorig, perm.data(), m);
-    if (e == hipSuccess) e = to_device(&ix->d_maxlen, maxlen.data(), n_groups);
+    if (e == hipSuccess) e = to_device(&ix->d_dir_start, dir_s.data(), dir_s.size());
+    if (e == hipSuccess) e = to_device(&ix->d_dir_stop, dir_t.data(), dir_t.size());
     if (e != hipSuccess) {
         gams_index_destroy(h, ix);
         return gams_fail(h, e == hipErrorOutOfMemory ? GAMS_ENOMEM : GAMS_EHIP,
@@ -229,13 +310,13 @@ void gams_index_destroy(gams_gpu_t *h, gams_index_t *ix) {
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->compute);
     }
-    (void)hipFree(ix->d_off);
-    (void)hipFree(ix->d_starts);
+    (void)hipFree(ix->d_groups);
     (void)hipFree(ix->d_stops);
     (void)hipFree(ix->d_lstart);
     (void)hipFree(ix->d_lstop);
     (void)hipFree(ix->d_lorig);
-    (void)hipFree(ix->d_maxlen);
+    (void)hipFree(ix->d_dir_start);
+    (void)hipFree(ix->d_dir_stop);
     delete ix;
 }
 
@@ -262,7 +343,8 @@ int gams_gpu_count(gams_gpu_t *h, gams_index_t *ix, const uint32_t *group, const
     Q_HIP(qb.in(&d_o, (const int32_t *)nullptr, nq, h->compute));
     Q_HIP(hipEventRecord(h->k0, h->compute));
     hipLaunchKernelGGL(interval_count_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->compute,
-                       ix->d_off, ix->d_starts, ix->d_stops, ix->n_groups, d_g, d_s, d_e, nq, d_o);
+                       ix->d_groups, ix->d_lstart, ix->d_stops, ix->d_dir_start, ix->d_dir_stop, ix->n_groups, d_g,
+                       d_s, d_e, nq, d_o);
     Q_HIP(hipGetLastError());
     Q_HIP(hipEventRecord(h->k1, h->compute));
     h->k_valid = true;
@@ -287,8 +369,8 @@ int gams_gpu_locate(gams_gpu_t *h, gams_index_t *ix, const uint32_t *group, cons
     Q_HIP(qb.in(&d_o, (const int64_t *)nullptr, nq, h->compute));
     Q_HIP(hipEventRecord(h->k0, h->compute));
     hipLaunchKernelGGL(interval_locate_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->compute,
-                       ix->d_off, ix->d_lstart, ix->d_lstop, ix->d_lorig, ix->d_maxlen, ix->n_groups, d_g, d_s,
-                       d_e, nq, d_o);
+                       ix->d_groups, ix->d_lstart, ix->d_lstop, ix->d_lorig, ix->d_dir_start, ix->n_groups, d_g,
+                       d_s, d_e, nq, d_o);
     Q_HIP(hipGetLastError());
     Q_HIP(hipEventRecord(h->k1, h->compute));
     h->k_valid = true;
@@ -305,6 +387,8 @@ int gams_spans_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
     std::vector<uint64_t> cum(m);
     for (uint32_t g = 0; g < n_groups; ++g) {
         if (group_off[g] > group_off[g + 1]) return gams_fail(h, GAMS_EINVAL, "spans_create: group_off not ascending");
+        if (group_off[g + 1] - group_off[g] > 0xfffffff0ull)
+            return gams_fail(h, GAMS_EUNSUPPORTED, "spans_create: a group holds more than 2^32-16 spans");
         uint64_t c = 0;
         for (uint64_t i = group_off[g]; i < group_off[g + 1]; ++i) {
             if (hi[i] < lo[i] || (i > group_off[g] && lo[i] <= hi[i - 1]))
@@ -313,14 +397,26 @@ int gams_spans_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
             c += (uint64_t)((int64_t)hi[i] - lo[i] + 1);
         }
     }
+    std::vector<SpanGroup> groups(std::max<uint32_t>(n_groups, 1));
+    std::vector<uint32_t> dir(m + n_groups + 1);
+    for_groups(n_groups, [&](uint32_t g) {
+        const uint64_t o = group_off[g];
+        const uint32_t n = (uint32_t)(group_off[g + 1] - o);
+        std::vector<uint32_t> biased(n);
+        for (uint32_t i = 0; i < n; ++i) biased[i] = (uint32_t)lo[o + i] ^ 0x80000000u;
+        groups[g].off = o;
+        groups[g].n = n;
+        groups[g].lo = build_dir(biased.data(), n, dir.data() + o + g);
+    });
     GAMS_HIP(h, hipSetDevice(h->device));
     gams_spans_t *sp = new gams_spans_t();
     sp->n_groups = n_groups;
     sp->m = m;
-    hipError_t e = to_device(&sp->d_off, group_off, (size_t)n_groups + 1);
+    hipError_t e = to_device(&sp->d_groups, groups.data(), groups.size());
     if (e == hipSuccess) e = to_device(&sp->d_lo, lo, m);
     if (e == hipSuccess) e = to_device(&sp->d_hi, hi, m);
     if (e == hipSuccess) e = to_device(&sp->d_cum, cum.data(), m);
+    if (e == hipSuccess) e = to_device(&sp->d_dir_lo, dir.data(), dir.size());
     if (e != hipSuccess) {
         gams_spans_destroy(h, sp);
         return gams_fail(h, e == hipErrorOutOfMemory ? GAMS_ENOMEM : GAMS_EHIP,
@@ -336,7 +432,8 @@ void gams_spans_destroy(gams_gpu_t *h, gams_spans_t *sp) {
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->compute);
     }
-    (void)hipFree(sp->d_off);
+    (void)hipFree(sp->d_groups);
+    (void)hipFree(sp->d_dir_lo);
     (void)hipFree(sp->d_lo);
     (void)hipFree(sp->d_hi);
     (void)hipFree(sp->d_cum);
@@ -362,8 +459,8 @@ int gams_gpu_cover(gams_gpu_t *h, gams_spans_t *sp, const uint32_t *group, const
     Q_HIP(qb.in(&d_o, (const float *)nullptr, nq, h->compute));
     Q_HIP(hipEventRecord(h->k0, h->compute));
     hipLaunchKernelGGL(span_cover_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->compute,
-                       sp->d_off, sp->d_lo, sp->d_hi, sp->d_cum, sp->n_groups, d_g, d_cl, d_ch, d_s, d_e, nq,
-                       d_o);
+                       sp->d_groups, sp->d_lo, sp->d_hi, sp->d_cum, sp->d_dir_lo, sp->n_groups, d_g, d_cl, d_ch,
+                       d_s, d_e, nq, d_o);
     Q_HIP(hipGetLastError());
     Q_HIP(hipEventRecord(h->k1, h->compute));
     h->k_valid = true;

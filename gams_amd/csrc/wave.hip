@@ -1110,8 +1110,10 @@ int wave_upload_geometry(gams_gpu_t *h, gams_wave_plan_t *p) {
         // a slot of tw/8 records per tile (typical density is 1-2 % of the windows); a tile that
         // overflows makes gams_wave_peaks() regrow the slots to tw records and run again
         (void)hipFree(p->d_peaks);
-    (void)hipFree(p->d_dense);
+        (void)hipFree(p->d_dense);
         p->d_peaks = nullptr;
+        p->d_dense = nullptr;
+        p->dense_cap = 0;
         p->tile_cap = std::max<uint32_t>(p->tile_cap_req ? p->tile_cap_req : p->tw / 8u, 16u);
         GAMS_HIP(h, hipMalloc(&p->d_peaks, nt * (size_t)p->tile_cap * sizeof(gams_peak_t)));
     }
@@ -1241,6 +1243,8 @@ void gams_wave_plan_destroy(gams_gpu_t *h, gams_wave_plan_t *p) {
     (void)hipFree(p->d_ctgs);
     (void)hipFree(p->d_tiles);
     (void)hipFree(p->d_peaks);
+    (void)hipFree(p->d_dense);
+    if (p->done) (void)hipEventDestroy(p->done);
     (void)hipFree(p->d_counters);
     (void)hipFree(p->d_const_sig);
     (void)hipFree(p->d_stamps);

@@ -1,0 +1,137 @@
+"""Interval kernels through the C ABI on key distributions that stress the bucket directories:
+duplicates, one cluster plus an outlier, keys at 0 and 2^32-2, empty groups, negative span coordinates.
+Expected values: the oracle (rust-lapper / anno semantics) on every query."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gams_amd import engine
+from oracle import oracle as ora
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = engine.Engine(0)
+    yield e
+    e.close()
+
+
+def _groups(rng):
+    """list of (starts, stops) per group, unsorted, stop > start"""
+    out = []
+    out.append((np.zeros(0, np.uint32), np.zeros(0, np.uint32)))                      # empty group
+    out.append((np.array([7], np.uint32), np.array([8], np.uint32)))                  # single interval
+    a = np.full(500, 1000, np.uint32)                                                 # all starts equal
+    out.append((a, a + rng.integers(1, 50, 500).astype(np.uint32)))
+    a = np.concatenate([rng.integers(10, 20, 300), [4_000_000_000]]).astype(np.uint32)   # cluster + far outlier
+    out.append((a, a + 1))
+    a = np.concatenate([[0, 0, 1], rng.integers(0, 2**32 - 3000, 2000), [2**32 - 2]]).astype(np.uint32)
+    out.append((a, (a.astype(np.uint64) + rng.integers(1, 2000, a.size)).clip(max=2**32 - 1).astype(np.uint32)))
+    a = rng.integers(1, 1_000_000, 5000).astype(np.uint32)                            # the uniform case
+    out.append((a, a + rng.choice([1, 1, 1, 6, 300], 5000).astype(np.uint32)))
+    a = (np.arange(3000, dtype=np.uint32) * 2) ** 2 % 100_000 + 5                       # lumpy
+    out.append((a, a + 3))
+    out.append((np.zeros(0, np.uint32), np.zeros(0, np.uint32)))                      # empty group at the end
+    return out
+
+
+def _queries(rng, groups, n_each):
+    g_all, s_all, e_all = [], [], []
+    for g, (st, sp) in enumerate(groups):
+        edges = np.concatenate([st, sp, st - (st > 0), sp - 1, [0, 1, 2**32 - 2]]).astype(np.int64)
+        s = np.concatenate([rng.choice(edges, n_each), rng.integers(0, 2**32 - 1, n_each // 4)])
+        e = s + rng.choice([0, 1, 2, 50, 5000, 10**9], s.size)
+        s = s.clip(0, 2**32 - 2)
+        e = e.clip(0, 2**32 - 2)
+        g_all.append(np.full(s.size, g))
+        s_all.append(s)
+        e_all.append(e)
+    g_all.append(np.full(8, len(groups) + 3))                                         # unknown group
+    s_all.append(np.arange(8))
+    e_all.append(np.arange(8) + 5)
+    order = rng.permutation(sum(x.size for x in g_all))
+    return (np.concatenate(g_all)[order].astype(np.uint32), np.concatenate(s_all)[order].astype(np.uint32),
+            np.concatenate(e_all)[order].astype(np.uint32))
+
+
+def test_count_and_locate_on_skewed_keys(eng):
+    rng = np.random.default_rng(77)
+    groups = _groups(rng)
+    off = np.cumsum([0] + [g[0].size for g in groups]).astype(np.uint64)
+    starts = np.concatenate([g[0] for g in groups]).astype(np.uint32)
+    stops = np.concatenate([g[1] for g in groups]).astype(np.uint32)
+    ix = C.c_void_p()
+    eng.check(eng.lib.gams_index_create(eng.h, len(groups), off.ctypes.data, starts.ctypes.data, stops.ctypes.data,
+                                        C.byref(ix)))
+    qg, qs, qe = _queries(rng, groups, 600)
+    cnt = np.full(qg.size, -99, np.int32)
+    hit = np.full(qg.size, -99, np.int64)
+    eng.check(eng.lib.gams_gpu_count(eng.h, ix, qg.ctypes.data, qs.ctypes.data, qe.ctypes.data, qg.size,
+                                     cnt.ctypes.data))
+    eng.check(eng.lib.gams_gpu_locate(eng.h, ix, qg.ctypes.data, qs.ctypes.data, qe.ctypes.data, qg.size,
+                                      hit.ctypes.data))
+    eng.lib.gams_index_destroy(eng.h, ix)
+    for g, (st, sp) in enumerate(groups):
+        sel = np.flatnonzero(qg == g)
+        ss, tt = np.sort(st), np.sort(sp)
+        # Lapper::count in closed form, then the oracle itself on a sample
+        exp = (np.searchsorted(ss, qe[sel], "left").astype(np.int64)
+               - np.searchsorted(tt, qs[sel].astype(np.uint64) + 1, "left"))
+        assert np.array_equal(cnt[sel], exp), g
+        order = np.lexsort((sp, st))
+        ls, lt = st[order], sp[order]
+        for q in sel[:150]:
+            assert cnt[q] == ora.lapper_count(ss, tt, int(qs[q]), int(qe[q]))
+            k = ora.lapper_find_first(ls, lt, int(qs[q]), int(qe[q]))
+            if k < 0:
+                assert hit[q] == -1
+            else:
+                # equal (start, stop) pairs are interchangeable: compare the interval, not the index
+                j = int(hit[q]) - int(off[g])
+                assert (st[j], sp[j]) == (ls[k], lt[k]), (g, q)
+    unknown = qg >= len(groups)
+    assert np.all(cnt[unknown] == 0) and np.all(hit[unknown] == -1)
+
+
+def test_cover_on_skewed_and_negative_spans(eng):
+    rng = np.random.default_rng(78)
+    sets = []
+    sets.append((np.zeros(0, np.int32), np.zeros(0, np.int32)))
+    sets.append((np.array([-2_000_000_000], np.int32), np.array([-1_999_999_000], np.int32)))
+    cuts = np.sort(rng.choice(np.arange(-50_000, 50_000), 3000, replace=False))
+    sets.append((cuts[0::2].astype(np.int32), (cuts[1::2] - 1).astype(np.int32)))
+    lo = np.concatenate([np.arange(100, 400, 3), [2_000_000_000]]).astype(np.int32)      # cluster + outlier
+    sets.append((lo, (lo + np.concatenate([np.ones(100, np.int32), [100]])).astype(np.int32)))
+    keep = [s[1] >= s[0] for s in sets]
+    sets = [(s[0][k], s[1][k]) for s, k in zip(sets, keep)]
+    off = np.cumsum([0] + [s[0].size for s in sets]).astype(np.uint64)
+    lo = np.concatenate([s[0] for s in sets]).astype(np.int32)
+    hi = np.concatenate([s[1] for s in sets]).astype(np.int32)
+    sp = C.c_void_p()
+    eng.check(eng.lib.gams_spans_create(eng.h, len(sets), off.ctypes.data, lo.ctypes.data, hi.ctypes.data,
+                                        C.byref(sp)))
+    n = 6000
+    g = rng.integers(0, len(sets) + 1, n).astype(np.uint32)                            # len(sets) = chr not in the set
+    s = np.empty(n, np.int64)
+    for i in range(n):
+        pool = np.concatenate([sets[g[i]][0], sets[g[i]][1], [0]]) if g[i] < len(sets) else np.array([0])
+        s[i] = int(rng.choice(pool)) + int(rng.integers(-3, 4))
+    e = s + rng.choice([0, 1, 99, 3000, 10**6], n)
+    s = s.clip(-2**31 + 1, 2**31 - 2).astype(np.int32)
+    e = e.clip(s, 2**31 - 2).astype(np.int32)
+    cl = (s.astype(np.int64) - rng.choice([0, 10, 10**5, 10**9], n)).clip(-2**31, 2**31 - 1).astype(np.int32)
+    ch = (e.astype(np.int64) + rng.choice([-1, 0, 10, 10**9], n)).clip(-2**31, 2**31 - 1).astype(np.int32)
+    prop = np.full(n, -1, np.float32)
+    eng.check(eng.lib.gams_gpu_cover(eng.h, sp, g.ctypes.data, cl.ctypes.data, ch.ctypes.data, s.ctypes.data,
+                                     e.ctypes.data, n, prop.ctypes.data))
+    eng.lib.gams_spans_destroy(eng.h, sp)
+    for i in range(n):
+        if g[i] >= len(sets):
+            assert prop[i] == 0.0
+            continue
+        slo, shi = sets[g[i]]
+        exp = ora.anno_prop(slo, shi, int(cl[i]), int(ch[i]), int(s[i]), int(e[i]))
+        assert prop[i] == np.float32(exp), (i, g[i], s[i], e[i], cl[i], ch[i])

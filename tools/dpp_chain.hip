@@ -20,7 +20,20 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *cyc, in
             else if (mode == 1) asm volatile(R15(STEP0) "s_nop 1\n\t" : "+v"(s) : "v"(x));
             else if (mode == 2) asm volatile(R15(STEP2) : "+v"(s), "+v"(d1), "+v"(d2) : "v"(x));
             else if (mode == 3) asm volatile(R15(STEP3) : "+v"(s) : "v"(x));
-            else asm volatile(R15(STEP4) : "+v"(s), "+v"(d1) : "v"(x));
+            else if (mode == 4) asm volatile(R15(STEP4) : "+v"(s), "+v"(d1) : "v"(x));
+            else if (mode == 5) {
+#pragma unroll
+                for (int q = 0; q < 15; ++q) asm volatile("v_add_f32 %0, %0, %1\n\t" : "+v"(s) : "v"(x));
+            } else if (mode == 6) {
+                // lane values -> SGPRs (independent v_readlane), chain of plain v_add_f32 with an SGPR operand
+#pragma unroll
+                for (int q = 0; q < 15; ++q)
+                    s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), (r * 15 + q) & 63));
+            } else {
+#pragma unroll
+                for (int q = 0; q < 15; ++q) s = s + x;                      // compiler's own dependent chain
+                asm volatile("" : "+v"(s));
+            }
         }
         s += d1 + d2;
         unsigned long long t1 = __builtin_readcyclecounter();
@@ -36,7 +49,7 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *cyc, in
 int main() {
     float *d; unsigned long long *c;
     hipMalloc(&d, 256 * 8 * 256 * 4); hipMalloc(&c, 2048 * 8);
-    for (int mode = 0; mode < 5; ++mode)
+    for (int mode = 0; mode < 8; ++mode)
         for (int ny : {1, 5}) {
             hipLaunchKernelGGL(k, dim3(256, ny), dim3(256), 0, 0, d, c, mode, 20000);
             hipDeviceSynchronize();
@@ -44,7 +57,7 @@ int main() {
             hipMemcpy(h.data(), c, 256 * 8, hipMemcpyDeviceToHost);
             double m = 0; for (auto v : h) m += v; m /= 256;
             printf("mode %d (%s), %d workgroups per CU: %.0f cycles for 210 steps = %.1f per step\n", mode,
-                   mode == 0 ? "s_nop 1 + add_dpp" : mode == 1 ? "add_dpp back to back (hazard!)" : mode == 2 ? "2 v_mov fillers" : mode == 3 ? "s_nop 0" : "1 v_mov filler", ny, m, m / 210);
+                   mode == 0 ? "s_nop 1 + add_dpp" : mode == 1 ? "add_dpp back to back (hazard!)" : mode == 2 ? "2 v_mov fillers" : mode == 3 ? "s_nop 0" : mode == 4 ? "1 v_mov filler" : mode == 5 ? "plain dependent v_add_f32" : mode == 6 ? "v_readlane -> SGPR + v_add_f32" : "s = s + x", ny, m, m / 210);
         }
     return 0;
 }
