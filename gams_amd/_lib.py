@@ -47,6 +47,7 @@ PROTOTYPES = {
     "gams_window_count": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     "gams_seqset_create": (C.c_int, [_VP, C.c_uint32, _VP, _PP]),
     "gams_seqset_upload": (C.c_int, [_VP, _VP, C.c_uint32, _VP]),
+    "gams_seqset_upload_all": (C.c_int, [_VP, _VP, _VP]),
     "gams_seqset_destroy": (None, [_VP, _VP]),
     "gams_wave_plan_create": (C.c_int, [_VP, _VP, C.POINTER(WaveParams), C.c_uint32, _PP]),
     "gams_wave_plan_destroy": (None, [_VP, _VP]),

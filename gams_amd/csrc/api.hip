@@ -3,6 +3,8 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 
 extern "C" {
 
@@ -36,6 +38,8 @@ int gams_gpu_create(int device, gams_gpu_t **out) {
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&h->k0)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&h->k1)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->pin_scratch), 4096, hipHostMallocDefault)) != hipSuccess)
+        return bail(e, "hipHostMalloc(scratch)");
     *out = h;
     return GAMS_OK;
 }
@@ -63,6 +67,9 @@ void gams_gpu_destroy(gams_gpu_t *h) {
         if (h->stage[k]) (void)hipHostFree(h->stage[k]);
         if (h->stage_free[k]) (void)hipEventDestroy(h->stage_free[k]);
     }
+    if (h->pin_scratch) (void)hipHostFree(h->pin_scratch);
+    for (auto &b : h->dev_pool) (void)hipFree(b.p);
+    for (auto &b : h->pin_pool) (void)hipHostFree(b.p);
     delete h;
 }
 
@@ -127,20 +134,24 @@ int gams_seqset_create(gams_gpu_t *h, uint32_t n_ctg, const uint32_t *lengths, g
         o += ((uint64_t)lengths[i] + 255u) & ~(uint64_t)255u;  // next ctg on a 256-B boundary
     }
     s->bytes = o + 65536;  // tail slack: kernels read whole 16-B chunks, the baked wave kernels whole 4-KiB rows
-    hipError_t e = hipMalloc(&s->d_seq, s->bytes);
+    hipError_t e = gams_pool_alloc(h, false, s->bytes, reinterpret_cast<void **>(&s->d_seq), &s->cap);
     if (e != hipSuccess) {
         delete s;
         return gams_fail(h, e == hipErrorOutOfMemory ? GAMS_ENOMEM : GAMS_EHIP,
                          std::string("seqset_create: hipMalloc: ") + hipGetErrorString(e));
     }
-    // padding bytes are never counted, but keep them defined
+    // Padding bytes are never counted, but keep them defined (the block may be a recycled one).
+    // Queued on the copy stream in front of the uploads; nothing waits for it on the host.
     e = hipMemsetAsync(s->d_seq, 0, s->bytes, h->copy);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->copy);
     if (e != hipSuccess) {
-        (void)hipFree(s->d_seq);
+        gams_pool_free(h, false, s->d_seq, s->cap);
         delete s;
         return gams_fail(h, GAMS_EHIP, std::string("seqset_create: memset: ") + hipGetErrorString(e));
     }
+    // readers on the compute stream order themselves behind the memset like behind an upload
+    if (hipEventCreateWithFlags(&s->uploaded, hipEventDisableTiming) == hipSuccess &&
+        hipEventRecord(s->uploaded, h->copy) == hipSuccess)
+        s->dirty = true;
     *out = s;
     return GAMS_OK;
 }
@@ -157,12 +168,9 @@ int gams_seqset_upload(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, const uint8_
     // Pageable host memory -> pinned ring -> HBM: the call returns once the last piece is queued;
     // the host memcpy of piece k+1 overlaps the DMA of piece k.  Kernels that read the seqset
     // wait on s->uploaded (gams_seqset_wait_uploads), not the host.
-    for (int k = 0; k < gams_gpu::kStageSlots; ++k) {
-        if (!h->stage[k]) {
-            GAMS_HIP(h, hipHostMalloc(reinterpret_cast<void **>(&h->stage[k]), gams_gpu::kStageBytes, hipHostMallocDefault));
-            GAMS_HIP(h, hipEventCreateWithFlags(&h->stage_free[k], hipEventDisableTiming));
-            GAMS_HIP(h, hipEventRecord(h->stage_free[k], h->copy));
-        }
+    {
+        int rc = gams_stage_ring(h);
+        if (rc != GAMS_OK) return rc;
     }
     if (!s->uploaded) GAMS_HIP(h, hipEventCreateWithFlags(&s->uploaded, hipEventDisableTiming));
     const uint64_t len = s->len[i];
@@ -180,6 +188,75 @@ int gams_seqset_upload(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, const uint8_
     return GAMS_OK;
 }
 
+int gams_seqset_upload_all(gams_gpu_t *h, gams_seqset_t *s, const uint8_t *const *seqs) {
+    if (!h || !s || (s->n_ctg && !seqs)) return gams_fail(h, GAMS_EINVAL, "seqset_upload_all: null argument");
+    for (uint32_t i = 0; i < s->n_ctg; ++i)
+        if (s->len[i] && !seqs[i]) return gams_fail(h, GAMS_EINVAL, "seqset_upload_all: null sequence");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    if (s->n_ctg == 0) return GAMS_OK;
+    if (s->gcindex) {
+        GAMS_HIP(h, hipStreamSynchronize(h->compute));
+        gams_seqset_gcindex_free(s);
+    }
+    {
+        int rc = gams_stage_ring(h);
+        if (rc != GAMS_OK) return rc;
+    }
+    if (!s->uploaded) GAMS_HIP(h, hipEventCreateWithFlags(&s->uploaded, hipEventDisableTiming));
+    // The staging slots mirror the device layout (ctgs on 256-B boundaries, gaps zeroed), so one
+    // window of kStageBytes is one DMA.  Worker t owns slot t and takes windows t, t+T, ...: its
+    // memcpy of the next window overlaps the DMAs the other workers queued.
+    const uint64_t end = s->off[s->n_ctg - 1] + s->len[s->n_ctg - 1];
+    // a small batch is cut finer so that all workers and the DMA engine still overlap
+    const uint64_t W = std::min<uint64_t>(gams_gpu::kStageBytes,
+                                          std::max<uint64_t>(1u << 20, (end / (2 * gams_gpu::kStageSlots) + 4095) & ~4095ull));
+    const uint64_t n_win = (end + W - 1) / W;
+    const unsigned T = (unsigned)std::min<uint64_t>(gams_gpu::kStageSlots, std::max<uint64_t>(n_win, 1));
+    std::atomic<int> failed{0};
+    std::string err[gams_gpu::kStageSlots];
+    auto work = [&](unsigned t) {
+        hipError_t e = hipSetDevice(h->device);
+        for (uint64_t w = t; w < n_win && e == hipSuccess && !failed.load(); w += T) {
+            const uint64_t lo = w * W, hi = std::min(end, lo + W);
+            e = hipEventSynchronize(h->stage_free[t]);              // the DMA that used this slot is done
+            if (e != hipSuccess) break;
+            uint8_t *dst = h->stage[t];
+            // first ctg whose bytes reach into the window
+            uint32_t i = (uint32_t)(std::upper_bound(s->off.begin(), s->off.end(), lo) - s->off.begin());
+            i = i ? i - 1 : 0;
+            uint64_t filled = lo;                                       // stage holds [lo, filled)
+            for (; i < s->n_ctg && s->off[i] < hi; ++i) {
+                const uint64_t a = std::max(lo, s->off[i]), b = std::min(hi, s->off[i] + s->len[i]);
+                if (a > filled) std::memset(dst + (filled - lo), 0, a - filled);   // alignment gap
+                if (b > a) {
+                    std::memcpy(dst + (a - lo), seqs[i] + (a - s->off[i]), b - a);
+                    filled = b;
+                } else if (a > filled) {
+                    filled = a;
+                }
+            }
+            if (hi > filled) std::memset(dst + (filled - lo), 0, hi - filled);
+            e = hipMemcpyAsync(s->d_seq + lo, dst, hi - lo, hipMemcpyHostToDevice, h->copy);
+            if (e == hipSuccess) e = hipEventRecord(h->stage_free[t], h->copy);
+        }
+        if (e != hipSuccess) {
+            err[t] = hipGetErrorString(e);
+            failed.store(1);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < T; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool) th.join();
+    if (failed.load()) {
+        for (auto &m : err)
+            if (!m.empty()) return gams_fail(h, GAMS_EHIP, "seqset_upload_all: " + m);
+    }
+    GAMS_HIP(h, hipEventRecord(s->uploaded, h->copy));
+    s->dirty = true;
+    return GAMS_OK;
+}
+
 void gams_seqset_destroy(gams_gpu_t *h, gams_seqset_t *s) {
     if (!s) return;
     if (h) {
@@ -189,11 +266,69 @@ void gams_seqset_destroy(gams_gpu_t *h, gams_seqset_t *s) {
     if (h) (void)hipStreamSynchronize(h->copy);
     gams_seqset_gcindex_free(s);
     if (s->uploaded) (void)hipEventDestroy(s->uploaded);
-    (void)hipFree(s->d_seq);
+    gams_pool_free(h, false, s->d_seq, s->cap);
     delete s;
 }
 
 }  // extern "C"
+
+hipError_t gams_pool_alloc(gams_gpu_t *h, bool pinned, size_t bytes, void **out, size_t *cap) {
+    auto &pool = pinned ? h->pin_pool : h->dev_pool;
+    bytes = std::max<size_t>(bytes, 1);
+    // best fit among the kept blocks, but never hand a huge block to a small request
+    int best = -1;
+    for (int i = 0; i < (int)pool.size(); ++i)
+        if (pool[i].bytes >= bytes && pool[i].bytes <= std::max<size_t>(2 * bytes, 4u << 20) &&
+            (best < 0 || pool[i].bytes < pool[best].bytes))
+            best = i;
+    if (best >= 0) {
+        *out = pool[best].p;
+        *cap = pool[best].bytes;
+        pool.erase(pool.begin() + best);
+        return hipSuccess;
+    }
+    const size_t want = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);   // 2-MiB granules
+    hipError_t e = pinned ? hipHostMalloc(out, want, hipHostMallocDefault) : hipMalloc(out, want);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        for (auto &b : pool) (void)(pinned ? hipHostFree(b.p) : hipFree(b.p));
+        pool.clear();
+        e = pinned ? hipHostMalloc(out, want, hipHostMallocDefault) : hipMalloc(out, want);
+    }
+    if (e == hipSuccess) *cap = want;
+    return e;
+}
+
+void gams_pool_free(gams_gpu_t *h, bool pinned, void *p, size_t cap) {
+    if (!p) return;
+    if (!h) {
+        (void)(pinned ? hipHostFree(p) : hipFree(p));
+        return;
+    }
+    auto &pool = pinned ? h->pin_pool : h->dev_pool;
+    pool.push_back({p, cap});
+    // keep at most 16 blocks and a quarter of the HBM (1 GiB of pinned memory): drop the oldest
+    const size_t limit = pinned ? ((size_t)1 << 30) : (size_t)(h->hbm / 4);
+    size_t total = 0;
+    for (auto &b : pool) total += b.bytes;
+    while (!pool.empty() && (pool.size() > 16 || total > limit)) {
+        total -= pool.front().bytes;
+        (void)(pinned ? hipHostFree(pool.front().p) : hipFree(pool.front().p));
+        pool.erase(pool.begin());
+    }
+}
+
+// the pinned staging ring, allocated on first use
+int gams_stage_ring(gams_gpu_t *h) {
+    for (int k = 0; k < gams_gpu::kStageSlots; ++k) {
+        if (!h->stage[k]) {
+            GAMS_HIP(h, hipHostMalloc(reinterpret_cast<void **>(&h->stage[k]), gams_gpu::kStageBytes, hipHostMallocDefault));
+            GAMS_HIP(h, hipEventCreateWithFlags(&h->stage_free[k], hipEventDisableTiming));
+            GAMS_HIP(h, hipEventRecord(h->stage_free[k], h->copy));
+        }
+    }
+    return GAMS_OK;
+}
 
 int gams_seqset_wait_uploads(gams_gpu_t *h, gams_seqset_t *s) {
     if (s->dirty) {

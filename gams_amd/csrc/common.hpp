@@ -20,16 +20,29 @@ struct gams_gpu {
     hipEvent_t k0 = nullptr, k1 = nullptr;  // around the kernel of the last query-style call
     bool k_valid = false;
     // pinned staging ring of the copy stream: the CPU fills slot k+1 while the DMA drains slot k
-    static constexpr int kStageSlots = 2;
+    static constexpr int kStageSlots = 4;
     static constexpr size_t kStageBytes = 16u << 20;
-    uint8_t *stage[kStageSlots] = {nullptr, nullptr};
-    hipEvent_t stage_free[kStageSlots] = {nullptr, nullptr};
+    uint8_t *stage[kStageSlots] = {};
+    hipEvent_t stage_free[kStageSlots] = {};
     int stage_next = 0;
+    unsigned long long *pin_scratch = nullptr;   // 4 KiB of pinned host memory for few-word readbacks
     int cus = 0;
     uint64_t hbm = 0;
     char arch[64] = {0};
     std::string err;
+    // Freed HBM / pinned-host blocks kept for the next batch: hipMalloc of a few hundred MB and
+    // hipHostMalloc of the peak buffer cost milliseconds each (13 ms + 5 ms per 384-Mb batch).
+    struct Block {
+        void *p;
+        size_t bytes;
+    };
+    std::vector<Block> dev_pool, pin_pool;
 };
+
+// Pooled allocation on the handle's device (pinned = page-locked host memory).  *cap is the size
+// of the block handed out (>= bytes); pass it back to gams_pool_free.
+hipError_t gams_pool_alloc(gams_gpu_t *h, bool pinned, size_t bytes, void **out, size_t *cap);
+void gams_pool_free(gams_gpu_t *h, bool pinned, void *p, size_t cap);
 
 inline int gams_fail(gams_gpu_t *h, int code, const std::string &msg) {
     if (h) h->err = msg;
@@ -51,7 +64,8 @@ struct gams_seqset {
     uint32_t n_ctg = 0;
     std::vector<uint32_t> len;      // bases per ctg
     std::vector<uint64_t> off;      // byte offset of ctg i inside d_seq (256-B aligned)
-    uint64_t bytes = 0;             // allocation size (with tail slack for 16-B over-reads)
+    uint64_t bytes = 0;             // bytes in use (with tail slack for 16-B over-reads)
+    size_t cap = 0;                 // size of the pooled block behind d_seq
     uint8_t *d_seq = nullptr;
     hipEvent_t uploaded = nullptr;    // recorded on the copy stream after the last upload; kernels wait on it
     bool dirty = false;               // an upload happened since the last wait was queued
@@ -60,6 +74,7 @@ struct gams_seqset {
 
 // make the compute stream wait for every upload queued so far (no host blocking)
 int gams_seqset_wait_uploads(gams_gpu_t *h, gams_seqset_t *s);
+int gams_stage_ring(gams_gpu_t *h);   // allocate the pinned staging slots on first use
 int gams_seqset_gcindex(gams_gpu_t *h, gams_seqset_t *s);
 void gams_seqset_gcindex_free(gams_seqset_t *s);
 

@@ -913,14 +913,57 @@ __global__ __launch_bounds__(256) void wave_compact_kernel(const WaveCtgDev *ctg
     }
 }
 
-// Pack the per-tile slots into one dense, (ctg, window)-ordered array: one wave per tile.
+// Exclusive prefix of the per-tile peak counts -> tile_off; totals[0] = all peaks, totals[1] = the
+// fullest tile.  One workgroup of 1024 lanes, each summing a contiguous run of tiles.
+__global__ __launch_bounds__(1024) void wave_offsets_kernel(const uint32_t *tile_cnt, uint32_t nt,
+                                                            unsigned long long *tile_off,
+                                                            unsigned long long *totals) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ uint32_t wmax[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t per = (nt + 1023u) / 1024u;
+    const uint32_t t0 = min(nt, tid * per), t1 = min(nt, t0 + per);
+    unsigned long long mine = 0;
+    uint32_t mx = 0;
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t c = tile_cnt[t];
+        mine += c;
+        mx = max(mx, c);
+    }
+    unsigned long long inc = wave_incl_scan_u64(mine);
+    for (int d = 32; d; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    if (lane == 63) wsum[wv] = inc;
+    if (lane == 0) wmax[wv] = mx;
+    __syncthreads();
+    unsigned long long base = 0, all = 0;
+    uint32_t worst = 0;
+    for (uint32_t w = 0; w < 16; ++w) {
+        if (w < wv) base += wsum[w];
+        all += wsum[w];
+        worst = max(worst, wmax[w]);
+    }
+    unsigned long long off = base + inc - mine;
+    for (uint32_t t = t0; t < t1; ++t) {
+        tile_off[t] = off;
+        off += tile_cnt[t];
+    }
+    if (tid == 0) {
+        totals[0] = all;
+        totals[1] = worst;
+    }
+}
+
+// Pack the per-tile slots into one dense, (ctg, window)-ordered array: one wave per tile.  A tile
+// that would not fit `cap` records (or overflowed its slot) is skipped: the host regrows and repeats.
 __global__ __launch_bounds__(64) void wave_gather_kernel(const gams_peak_t *slots, uint32_t tile_cap,
                                                          const uint32_t *tile_cnt, const unsigned long long *tile_off,
-                                                         gams_peak_t *dense) {
+                                                         gams_peak_t *dense, unsigned long long cap) {
     const uint32_t t = blockIdx.x;
     const uint32_t n = tile_cnt[t];
+    const unsigned long long o = tile_off[t];
+    if (n > tile_cap || o + n > cap) return;
     const gams_peak_t *src = slots + (size_t)t * tile_cap;
-    gams_peak_t *dst = dense + tile_off[t];
+    gams_peak_t *dst = dense + o;
     for (uint32_t i = threadIdx.x; i < n; i += 64u) dst[i] = src[i];
 }
 
@@ -945,7 +988,10 @@ struct gams_wave_plan {
     // device
     WaveCtgDev *d_ctgs = nullptr;
     WaveTile *d_tiles = nullptr;
-    gams_peak_t *d_peaks = nullptr;             // one slot of tile_cap records per tile
+    gams_peak_t *d_peaks = nullptr;             // one slot of tile_cap records per tile (pooled block)
+    size_t d_peaks_bytes = 0, d_dense_bytes = 0;
+    gams_peak_t *h_peaks = nullptr;             // pinned: packed peaks of the last gams_wave_peaks
+    size_t h_peaks_bytes = 0;
     uint32_t tile_cap = 0, tile_cap_req = 0;
     gams_peak_t *d_dense = nullptr;             // packed copy made by gams_wave_peaks
     uint64_t dense_cap = 0;
@@ -956,13 +1002,15 @@ struct gams_wave_plan {
     unsigned long long *d_stamps = nullptr;     // diagnostics, [tiles][8]
     unsigned long long *d_tile_off = nullptr;
     uint32_t *d_tile_cnt = nullptr;
+    // two pooled arenas hold the small tables: `fixed` = ctgs | counters | const_sig (life of the
+    // plan), `geom` = tiles | tile_off (+2 totals) | tile_cnt (replaced when the tiling changes)
+    uint8_t *arena_fixed = nullptr, *arena_geom = nullptr;
+    size_t arena_fixed_bytes = 0, arena_geom_bytes = 0;
     uint32_t *d_dense_cnt = nullptr;
     int8_t *d_dense_sig = nullptr;
     float *d_filtered = nullptr;
     // host results
-    std::vector<gams_peak_t> h_sorted;
-    std::vector<unsigned long long> h_tile_off;
-    std::vector<uint32_t> h_tile_cnt;
+    hipEvent_t ran_ev = nullptr;                // lets the readback stream queue behind the last run
     bool ran = false;
     hipEvent_t done = nullptr;    // pipelined mode: recorded behind each run's kernels, readers wait on it
     bool pipelined = false;       // gams_wave_plan_set_pipelined: off = readers synchronise the compute stream
@@ -1095,27 +1143,34 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
     return GAMS_OK;
 }
 
+inline size_t wave_align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
 int wave_upload_geometry(gams_gpu_t *h, gams_wave_plan_t *p) {
-    if (p->d_tiles) (void)hipFree(p->d_tiles);
-    if (p->d_tile_off) (void)hipFree(p->d_tile_off);
-    if (p->d_tile_cnt) (void)hipFree(p->d_tile_cnt);
+    gams_pool_free(h, false, p->arena_geom, p->arena_geom_bytes);
+    p->arena_geom = nullptr;
     p->d_tiles = nullptr;
     p->d_tile_off = nullptr;
     p->d_tile_cnt = nullptr;
     const size_t nt = std::max<size_t>(p->tiles.size(), 1);
-    GAMS_HIP(h, hipMalloc(&p->d_tiles, nt * sizeof(WaveTile)));
-    GAMS_HIP(h, hipMalloc(&p->d_tile_off, nt * sizeof(unsigned long long)));
-    GAMS_HIP(h, hipMalloc(&p->d_tile_cnt, nt * sizeof(uint32_t)));
+    const size_t b_tiles = wave_align256(nt * sizeof(WaveTile));
+    const size_t b_off = wave_align256((nt + 2) * sizeof(unsigned long long));   // + the two totals
+    const size_t b_cnt = wave_align256(nt * sizeof(uint32_t));
+    GAMS_HIP(h, gams_pool_alloc(h, false, b_tiles + b_off + b_cnt, reinterpret_cast<void **>(&p->arena_geom),
+                                &p->arena_geom_bytes));
+    p->d_tiles = reinterpret_cast<WaveTile *>(p->arena_geom);
+    p->d_tile_off = reinterpret_cast<unsigned long long *>(p->arena_geom + b_tiles);
+    p->d_tile_cnt = reinterpret_cast<uint32_t *>(p->arena_geom + b_tiles + b_off);
     if (p->flags & GAMS_WAVE_PEAKS) {
         // a slot of tw/8 records per tile (typical density is 1-2 % of the windows); a tile that
         // overflows makes gams_wave_peaks() regrow the slots to tw records and run again
-        (void)hipFree(p->d_peaks);
-        (void)hipFree(p->d_dense);
+        gams_pool_free(h, false, p->d_peaks, p->d_peaks_bytes);
+        gams_pool_free(h, false, p->d_dense, p->d_dense_bytes);
         p->d_peaks = nullptr;
         p->d_dense = nullptr;
         p->dense_cap = 0;
         p->tile_cap = std::max<uint32_t>(p->tile_cap_req ? p->tile_cap_req : p->tw / 8u, 16u);
-        GAMS_HIP(h, hipMalloc(&p->d_peaks, nt * (size_t)p->tile_cap * sizeof(gams_peak_t)));
+        GAMS_HIP(h, gams_pool_alloc(h, false, nt * (size_t)p->tile_cap * sizeof(gams_peak_t),
+                                    reinterpret_cast<void **>(&p->d_peaks), &p->d_peaks_bytes));
     }
     if (!p->tiles.empty())
         GAMS_HIP(h, hipMemcpy(p->d_tiles, p->tiles.data(), p->tiles.size() * sizeof(WaveTile),
@@ -1214,14 +1269,22 @@ int gams_wave_plan_create(gams_gpu_t *h, gams_seqset_t *s, const gams_wave_param
             return fail(GAMS_EHIP);                                                       \
         }                                                                                 \
     } while (0)
-    PLAN_HIP(hipMalloc(&p->d_ctgs, std::max<size_t>(s->n_ctg, 1) * sizeof(WaveCtgDev)));
+    {
+        const size_t b_ctgs = wave_align256(std::max<size_t>(s->n_ctg, 1) * sizeof(WaveCtgDev));
+        const size_t b_counters = wave_align256(kCounterRing * kSlotWords * sizeof(unsigned long long));
+        const size_t b_const = wave_align256((size_t)params->size + 1);
+        PLAN_HIP(gams_pool_alloc(h, false, b_ctgs + b_counters + b_const, reinterpret_cast<void **>(&p->arena_fixed),
+                                 &p->arena_fixed_bytes));
+        p->d_ctgs = reinterpret_cast<WaveCtgDev *>(p->arena_fixed);
+        p->d_counters = reinterpret_cast<unsigned long long *>(p->arena_fixed + b_ctgs);
+        p->d_const_sig = reinterpret_cast<int8_t *>(p->arena_fixed + b_ctgs + b_counters);
+    }
     if (s->n_ctg)
         PLAN_HIP(hipMemcpy(p->d_ctgs, p->ctgs.data(), s->n_ctg * sizeof(WaveCtgDev), hipMemcpyHostToDevice));
     rc = wave_upload_geometry(h, p);
     if (rc != GAMS_OK) return fail(rc);
-    PLAN_HIP(hipMalloc(&p->d_counters, kCounterRing * kSlotWords * sizeof(unsigned long long)));
-    PLAN_HIP(hipMemset(p->d_counters, 0, kCounterRing * kSlotWords * sizeof(unsigned long long)));
-    PLAN_HIP(hipMalloc(&p->d_const_sig, (size_t)params->size + 1));
+    // queued in front of the first run on the same stream
+    PLAN_HIP(hipMemsetAsync(p->d_counters, 0, kCounterRing * kSlotWords * sizeof(unsigned long long), h->compute));
     hipLaunchKernelGGL(wave_const_table_kernel, dim3((params->size + 256) / 256), dim3(256), 0, h->compute,
                        p->d_const_sig, (uint32_t)params->size, params->lag, params->threshold);
     PLAN_HIP(hipGetLastError());
@@ -1240,16 +1303,15 @@ void gams_wave_plan_destroy(gams_gpu_t *h, gams_wave_plan_t *p) {
     if (!p) return;
     if (h) (void)hipSetDevice(h->device);
     if (h && h->compute) (void)hipStreamSynchronize(h->compute);
-    (void)hipFree(p->d_ctgs);
-    (void)hipFree(p->d_tiles);
-    (void)hipFree(p->d_peaks);
-    (void)hipFree(p->d_dense);
+    gams_pool_free(h, false, p->arena_fixed, p->arena_fixed_bytes);
+    gams_pool_free(h, false, p->arena_geom, p->arena_geom_bytes);
+    if (h && h->readback) (void)hipStreamSynchronize(h->readback);
+    gams_pool_free(h, false, p->d_peaks, p->d_peaks_bytes);
+    gams_pool_free(h, false, p->d_dense, p->d_dense_bytes);
+    gams_pool_free(h, true, p->h_peaks, p->h_peaks_bytes);
     if (p->done) (void)hipEventDestroy(p->done);
-    (void)hipFree(p->d_counters);
-    (void)hipFree(p->d_const_sig);
+    if (p->ran_ev) (void)hipEventDestroy(p->ran_ev);
     (void)hipFree(p->d_stamps);
-    (void)hipFree(p->d_tile_off);
-    (void)hipFree(p->d_tile_cnt);
     (void)hipFree(p->d_dense_cnt);
     (void)hipFree(p->d_dense_sig);
     (void)hipFree(p->d_filtered);
@@ -1377,22 +1439,40 @@ int gams_wave_peaks(gams_gpu_t *h, gams_wave_plan_t *p, const gams_peak_t **peak
     if (!p->ran) return gams_fail(h, GAMS_ESTATE, "wave_peaks: no run to read");
     GAMS_HIP(h, hipSetDevice(h->device));
     const size_t nt = p->tiles.size();
+    if (nt == 0) {
+        *peaks = nullptr;
+        *n_peaks = 0;
+        return GAMS_OK;
+    }
+    unsigned long long *const d_totals = p->d_tile_off + nt;          // two words behind the offsets
     for (int attempt = 0; attempt < 2; ++attempt) {
-        {
-            int wrc = wave_wait_last_run(h, p);      // pipelined: this run only, later runs keep going
-            if (wrc != GAMS_OK) return wrc;
+        // The readback stream queues behind the run (pipelined: behind this plan's run only, later
+        // runs of other plans keep going); the host waits once, for the two totals.
+        if (p->pipelined && p->done) {
+            GAMS_HIP(h, hipStreamWaitEvent(h->readback, p->done, 0));
+        } else {
+            if (!p->ran_ev) GAMS_HIP(h, hipEventCreateWithFlags(&p->ran_ev, hipEventDisableTiming));
+            GAMS_HIP(h, hipEventRecord(p->ran_ev, h->compute));
+            GAMS_HIP(h, hipStreamWaitEvent(h->readback, p->ran_ev, 0));
         }
-        p->h_tile_cnt.resize(nt);
-        p->h_tile_off.resize(nt);
-        if (nt)
-            GAMS_HIP(h, hipMemcpy(p->h_tile_cnt.data(), p->d_tile_cnt, nt * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        uint64_t total = 0;
-        uint32_t worst = 0;
-        for (size_t t = 0; t < nt; ++t) {
-            p->h_tile_off[t] = total;
-            total += p->h_tile_cnt[t];
-            worst = std::max(worst, p->h_tile_cnt[t]);
+        if (!p->d_dense) {
+            // typical density is 1-3 % of the windows; a fuller result regrows below
+            const uint64_t want = p->total_windows / 16 + 4096;
+            GAMS_HIP(h, gams_pool_alloc(h, false, want * sizeof(gams_peak_t),
+                                        reinterpret_cast<void **>(&p->d_dense), &p->d_dense_bytes));
+            p->dense_cap = p->d_dense_bytes / sizeof(gams_peak_t);
         }
+        hipLaunchKernelGGL(wave_offsets_kernel, dim3(1), dim3(1024), 0, h->readback, p->d_tile_cnt, (uint32_t)nt,
+                           p->d_tile_off, d_totals);
+        GAMS_HIP(h, hipGetLastError());
+        hipLaunchKernelGGL(wave_gather_kernel, dim3((unsigned)nt), dim3(64), 0, h->readback, p->d_peaks,
+                           p->tile_cap, p->d_tile_cnt, p->d_tile_off, p->d_dense, (unsigned long long)p->dense_cap);
+        GAMS_HIP(h, hipGetLastError());
+        GAMS_HIP(h, hipMemcpyAsync(h->pin_scratch, d_totals, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                   h->readback));
+        GAMS_HIP(h, hipStreamSynchronize(h->readback));
+        const uint64_t total = h->pin_scratch[0];
+        const uint64_t worst = h->pin_scratch[1];
         if (worst > p->tile_cap) {
             // some tile signalled more windows than its slot holds: give every tile a slot of
             // tw records (the maximum possible) and run again
@@ -1402,24 +1482,32 @@ int gams_wave_peaks(gams_gpu_t *h, gams_wave_plan_t *p, const gams_peak_t **peak
             if (rc != GAMS_OK) return rc;
             continue;
         }
-        p->h_sorted.resize(total);
         if (total) {
             if (total > p->dense_cap) {
-                (void)hipFree(p->d_dense);
+                gams_pool_free(h, false, p->d_dense, p->d_dense_bytes);
                 p->d_dense = nullptr;
-                p->dense_cap = total + total / 4 + 1024;
-                GAMS_HIP(h, hipMalloc(&p->d_dense, p->dense_cap * sizeof(gams_peak_t)));
+                p->dense_cap = 0;
+                const uint64_t want = total + total / 4 + 1024;
+                GAMS_HIP(h, gams_pool_alloc(h, false, want * sizeof(gams_peak_t),
+                                            reinterpret_cast<void **>(&p->d_dense), &p->d_dense_bytes));
+                p->dense_cap = p->d_dense_bytes / sizeof(gams_peak_t);
+                hipLaunchKernelGGL(wave_gather_kernel, dim3((unsigned)nt), dim3(64), 0, h->readback, p->d_peaks,
+                                   p->tile_cap, p->d_tile_cnt, p->d_tile_off, p->d_dense,
+                                   (unsigned long long)p->dense_cap);
+                GAMS_HIP(h, hipGetLastError());
             }
-            GAMS_HIP(h, hipMemcpyAsync(p->d_tile_off, p->h_tile_off.data(), nt * sizeof(unsigned long long),
-                                       hipMemcpyHostToDevice, h->readback));
-            hipLaunchKernelGGL(wave_gather_kernel, dim3((unsigned)nt), dim3(64), 0, h->readback, p->d_peaks,
-                               p->tile_cap, p->d_tile_cnt, p->d_tile_off, p->d_dense);
-            GAMS_HIP(h, hipGetLastError());
-            GAMS_HIP(h, hipMemcpyAsync(p->h_sorted.data(), p->d_dense, total * sizeof(gams_peak_t),
+            if (total * sizeof(gams_peak_t) > p->h_peaks_bytes) {
+                gams_pool_free(h, true, p->h_peaks, p->h_peaks_bytes);
+                p->h_peaks = nullptr;
+                p->h_peaks_bytes = 0;
+                GAMS_HIP(h, gams_pool_alloc(h, true, (total + total / 4 + 1024) * sizeof(gams_peak_t),
+                                            reinterpret_cast<void **>(&p->h_peaks), &p->h_peaks_bytes));
+            }
+                GAMS_HIP(h, hipMemcpyAsync(p->h_peaks, p->d_dense, total * sizeof(gams_peak_t),
                                        hipMemcpyDeviceToHost, h->readback));
-            GAMS_HIP(h, hipStreamSynchronize(h->readback));
-        }
-        *peaks = p->h_sorted.data();
+                GAMS_HIP(h, hipStreamSynchronize(h->readback));
+            }
+        *peaks = p->h_peaks;   // NULL when there is none
         *n_peaks = total;
         return GAMS_OK;
     }

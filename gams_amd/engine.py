@@ -84,9 +84,16 @@ class SeqSet:
         p = C.c_void_p()
         eng.check(eng.lib.gams_seqset_create(eng.h, len(seqs), self.lengths.ctypes.data, C.byref(p)))
         self.p = p
-        for i, s in enumerate(seqs):
-            a = _u8(s)
-            eng.check(eng.lib.gams_seqset_upload(eng.h, self.p, i, a.ctypes.data))
+        arrs = [_u8(s) for s in seqs]
+        ptrs = (C.c_void_p * max(len(arrs), 1))(*[a.ctypes.data if a.size else None for a in arrs])
+        eng.check(eng.lib.gams_seqset_upload_all(eng.h, self.p, ptrs))
+
+    def upload(self, i, seq):
+        """replace ctg i (same length) with new bases"""
+        a = _u8(seq)
+        if a.size != int(self.lengths[i]):
+            raise ValueError("SeqSet.upload: length differs from the ctg's slot")
+        self.eng.check(self.eng.lib.gams_seqset_upload(self.eng.h, self.p, i, a.ctypes.data))
 
     def close(self):
         if getattr(self, "p", None):

@@ -2,6 +2,8 @@
 #include "gams_host.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <charconv>
 #include <cmath>
 #include <cstdio>
@@ -217,6 +219,32 @@ namespace {
 // kernels (compute stream, behind the upload event) and returns; finish() waits, fetches and
 // formats.  Starting batch k+1 before finishing batch k overlaps its upload with k's kernel and
 // k's host-side merge/formatting with k+1's kernel.
+// fn(i) for i in [0,n) on up to 8 host threads; the first exception is rethrown on the caller
+template <typename F>
+void parallel_for(uint32_t n, F fn) {
+    const unsigned T = std::max(1u, std::min({8u, std::thread::hardware_concurrency(), n / 4u}));
+    if (T <= 1) {
+        for (uint32_t i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::atomic<uint32_t> next{0};
+    std::exception_ptr err;
+    std::mutex mu;
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < T; ++t)
+        pool.emplace_back([&] {
+            try {
+                for (uint32_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!err) err = std::current_exception();
+                next.store(n);
+            }
+        });
+    for (auto &th : pool) th.join();
+    if (err) std::rethrow_exception(err);
+}
+
 struct WaveJob {
     gams_gpu_t *h;
     std::vector<Ctg> ctgs;
@@ -234,7 +262,7 @@ void WaveJob::start(const std::vector<const uint8_t *> &seqs) {
     std::vector<uint32_t> lens(n);
     for (uint32_t c = 0; c < n; ++c) lens[c] = (uint32_t)(ctgs[c].chr_end - ctgs[c].chr_start + 1);
     check(h, gams_seqset_create(h, n, lens.data(), &sg.s));
-    for (uint32_t c = 0; c < n; ++c) check(h, gams_seqset_upload(h, sg.s, c, seqs[c]));
+    check(h, gams_seqset_upload_all(h, sg.s, seqs.data()));
     gams_wave_params_t prm{a.size, a.step, a.lag, a.threshold, a.influence};
     check(h, gams_wave_plan_create(h, sg.s, &prm, a.signal ? GAMS_WAVE_DENSE : GAMS_WAVE_PEAKS, &pg.p));
     check(h, gams_wave_plan_set_pipelined(h, pg.p, 1));   // finish() waits for this job, not the stream
@@ -271,10 +299,19 @@ std::vector<std::string> WaveJob::finish() {
     const gams_peak_t *pk = nullptr;
     uint64_t np = 0;
     check(h, gams_wave_peaks(h, pg.p, &pk, &np));
-    uint64_t q = 0;
-    for (uint32_t c = 0; c < n; ++c) {                                  // wave.rs:169-211
-        uint64_t q1 = q;
-        while (q1 < np && pk[q1].ctg == c) ++q1;
+    // peaks arrive ordered by (ctg, window): slice per ctg, then merge + format the ctgs on a few
+    // host threads (the rows of one ctg depend on nothing else)
+    std::vector<uint64_t> first(n + 1, np);
+    {
+        uint64_t q = 0;
+        for (uint32_t c = 0; c < n; ++c) {
+            first[c] = q;
+            while (q < np && pk[q].ctg == c) ++q;
+        }
+        first[n] = q;
+    }
+    parallel_for(n, [&](uint32_t c) {                                   // wave.rs:169-211
+        const uint64_t q = first[c], q1 = first[c + 1];
         // crests and troughs separately (:172-186)
         std::vector<uint32_t> w[2];
         std::vector<uint64_t> src[2];
@@ -294,6 +331,7 @@ std::vector<std::string> WaveJob::finish() {
             }
         }
         std::string &o = out[c];
+        o.reserve((size_t)(q1 - q) * 24);
         for (uint64_t i = q; i < q1; ++i) {                             // window order (:191)
             const int64_t s = (int64_t)ctgs[c].chr_start + (int64_t)pk[i].window * a.step, e = s + a.size - 1;
             if (merged[i - q]) {
@@ -313,8 +351,7 @@ std::vector<std::string> WaveJob::finish() {
             o += std::to_string(pk[i].signal);
             o += '\n';
         }
-        q = q1;
-    }
+    });
     return out;
 }
 

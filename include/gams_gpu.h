@@ -75,6 +75,10 @@ int gams_seqset_create(gams_gpu_t *h, uint32_t n_ctg, const uint32_t *lengths,
 /* copy ctg `i` (lengths[i] bytes) host -> HBM on the handle's copy stream */
 int gams_seqset_upload(gams_gpu_t *h, gams_seqset_t *s, uint32_t i,
                        const uint8_t *seq);
+/* copy every ctg of the set (seqs[i] -> lengths[i] bytes; NULL allowed where lengths[i] == 0):
+ * the batch form of the per-ctg GET loop (wave.rs:134-136).  Several host threads fill pinned
+ * staging buffers in the device layout, one DMA per 16 MiB; returns once everything is queued. */
+int gams_seqset_upload_all(gams_gpu_t *h, gams_seqset_t *s, const uint8_t *const *seqs);
 void gams_seqset_destroy(gams_gpu_t *h, gams_seqset_t *s);
 
 /* ---- wave (GC windows + smoothed z-score) ------------------------------- */

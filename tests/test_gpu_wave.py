@@ -209,3 +209,37 @@ def test_peak_slots_regrow_when_every_window_signals(eng, s288c):
         assert len(plan.peaks()) == len(exp)
         plan.close()
     ss.close()
+
+
+def test_upload_all_ragged_batch_matches_per_ctg_content(eng):
+    """gams_seqset_upload_all: zero-length ctgs, ctgs crossing and ending on the 16-MiB staging
+    windows, and a later single-ctg replacement; content checked through range GC (utils.rs:141-162)."""
+    import ctypes as C
+
+    rng = np.random.default_rng(31)
+    lens = [0, 1000, (16 << 20) + 3, 0, 300, (16 << 20) - 1000 - 256 * 2 - 512, 5000, 1, 0]
+    alphabet = np.frombuffer(b"ACGTacgtNn", np.uint8)
+    seqs = [alphabet[rng.integers(0, alphabet.size, n)].tobytes() for n in lens]
+    ss = engine.SeqSet(eng, seqs)
+
+    def check(i, seq):
+        n = len(seq)
+        if n == 0:
+            return
+        rs = np.concatenate([[1, 1, n], rng.integers(1, n + 1, 200)]).astype(np.int32)
+        re = np.minimum(rs + rng.choice([0, 9, 99, 4999], rs.size), n).astype(np.int32)
+        re[1] = n
+        gc = np.zeros(rs.size, np.float32)
+        eng.check(eng.lib.gams_gpu_range_gc(eng.h, ss.p, i, 1, rs.ctypes.data, re.ctypes.data, rs.size,
+                                            gc.ctypes.data))
+        for a, b, g in zip(rs, re, gc):
+            assert g == np.float32(ora.range_gc_content(seq, 1, int(a), int(b))), (i, a, b)
+
+    for i, s in enumerate(seqs):
+        check(i, s)
+    new = alphabet[rng.integers(0, 4, lens[2])].tobytes()
+    ss.upload(2, new)
+    check(2, new)
+    check(1, seqs[1])
+    check(4, seqs[4])
+    ss.close()

@@ -25,3 +25,15 @@ for label, fn in (("one batch", lambda: host.wave(eng, ctgs)),
         best = min(best, time.perf_counter() - t0)
     print(f"{label}: {best * 1e3:.1f} ms for {bases} bases, {windows} windows, {out.count(chr(10))} rows -> "
           f"{windows / best / 1e9:.2f} G windows/s, {bases / best / 1e9:.2f} GB/s of sequence")
+
+small = [dict(id=c["id"], chr_id=c["chr_id"], chr_start=c["chr_start"], chr_end=c["chr_end"], seq=c["seq"])
+         for c in synth.genome_ctgs(synth.S288C_LENGTHS, 500000)]
+sb = sum(len(c["seq"]) for c in small)
+sw_ = sum((len(c["seq"]) - 100) // 10 + 1 for c in small)
+best = 1e9
+for _ in range(10):
+    t0 = time.perf_counter()
+    out = host.wave(eng, small)
+    best = min(best, time.perf_counter() - t0)
+print(f"S288c one batch: {best * 1e3:.2f} ms for {sb} bases, {sw_} windows, {out.count(chr(10))} rows -> "
+      f"{sw_ / best / 1e9:.2f} G windows/s, {sb / best / 1e9:.2f} GB/s of sequence")
