@@ -203,7 +203,7 @@ def main():
                 "launch_ms": launch_ms,
             },
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:             # the CPU legs run on rank 0 at N=1 only
             cpu_wps, used, done, res = cpu_baseline(ctgs, prm)
             # parity in the same run: peaks of the sampled ctgs against the oracle
             ok = True
