@@ -324,38 +324,66 @@ __global__ __launch_bounds__(256) void wave_tile_kernel(const WaveArgs a) {
 }
 
 // Same evaluation, executed by a whole wavefront for ONE window: the lanes fetch and
-// convert the lag counts in parallel; only the two f32 sums stay sequential, fed
-// lane by lane through v_readlane in the reference's order.  Every lane returns
-// the same signal.  Control flow must be wave-uniform at the call.
+// convert the lag counts in parallel; only the two f32 sums stay sequential, in the
+// reference's order.  Every lane returns the same signal.  Control flow must be wave-uniform
+// at the call.
 __device__ __forceinline__ float readlane_f32(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-// Sequential f32 sum of the first `m` lane values of `x` (m <= 64, wave-uniform) on top of
-// `carry`, in lane order.  Row by row (16 lanes): s <- row_shr:1(s) + x fifteen times, the row's
-// lane 0 keeping x + carry (a DPP lane without a source is left unchanged with bound_ctrl off);
-// after t steps lanes 0..t of the row hold carry + x_0 + ... + x_l accumulated strictly left to
-// right (f32 addition is commutative: prefix_{l-1} + x_l is what the reference computes) and
-// finished lanes no longer change.  The row's last lane is the next row's carry.  All four
-// rows run the instruction stream, only the current one matters.  One v_add_f32_dpp per
-// element; wave_shr:1 would need no row loop but measured ~25 cycles per dependent step.
-#define GAMS_SEQ_STEP "s_nop 1\n\tv_add_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-__device__ __forceinline__ float seq_add_lanes(float carry, float x, uint32_t m) {
-    for (uint32_t r = 0; r * 16u < m; ++r) {
-        float s = x + carry;   // lane 0 of every row; lanes past m hold x = 0
-        asm volatile(GAMS_SEQ_STEP GAMS_SEQ_STEP GAMS_SEQ_STEP GAMS_SEQ_STEP GAMS_SEQ_STEP GAMS_SEQ_STEP
-                         GAMS_SEQ_STEP GAMS_SEQ_STEP GAMS_SEQ_STEP GAMS_SEQ_STEP GAMS_SEQ_STEP GAMS_SEQ_STEP
-                             GAMS_SEQ_STEP GAMS_SEQ_STEP GAMS_SEQ_STEP
-                     : "+v"(s)
-                     : "v"(x));
-        carry = readlane_f32(s, (int)(r * 16u + 15u));
-    }
+// carry + x[B] + x[B+1] + ... + x[B+7] (lane values of x), added strictly left to right.
+// The eight lane values go to eight SGPRs first (v_readlane, independent of the sum), then one
+// plain dependent v_add_f32 per element with an SGPR operand: 8 + 8 issue slots per 8 elements.
+// The empty asm pins all eight in SGPRs before the first add, so that no add waits for its own
+// v_readlane (the compiler's single-SGPR version needs an s_nop 1 per element).
+// Cycles per lag-100 evaluation, alone on a SIMD (tools/dep_latency.hip): 2349, against 4952
+// for the row-DPP chain (s_nop 1 + v_add_f32_dpp row_shr:1 per element) this replaced and
+// 3733 for the single-SGPR form.  Inside the S288c launch an evaluation still costs ~4.9k
+// cycles (5.7k before): the code runs a few dozen times per launch, each time cold on its CU.
+// Tried and dropped: terms through LDS with broadcast ds_read_b128 + VGPR adds (8.4k cycles in
+// the kernel: the loop control eats the shorter chain), and inlining everything (scratch
+// spills under the 64-VGPR cap, 8.2 -> 11.7 us per launch).
+template <int B>
+__device__ __forceinline__ float seq_add8(float carry, float x) {
+    const int xi = __float_as_int(x);
+    int t0 = __builtin_amdgcn_readlane(xi, B + 0), t1 = __builtin_amdgcn_readlane(xi, B + 1),
+        t2 = __builtin_amdgcn_readlane(xi, B + 2), t3 = __builtin_amdgcn_readlane(xi, B + 3),
+        t4 = __builtin_amdgcn_readlane(xi, B + 4), t5 = __builtin_amdgcn_readlane(xi, B + 5),
+        t6 = __builtin_amdgcn_readlane(xi, B + 6), t7 = __builtin_amdgcn_readlane(xi, B + 7);
+    asm volatile("" : "+s"(t0), "+s"(t1), "+s"(t2), "+s"(t3), "+s"(t4), "+s"(t5), "+s"(t6), "+s"(t7));
+    carry = carry + __int_as_float(t0);
+    carry = carry + __int_as_float(t1);
+    carry = carry + __int_as_float(t2);
+    carry = carry + __int_as_float(t3);
+    carry = carry + __int_as_float(t4);
+    carry = carry + __int_as_float(t5);
+    carry = carry + __int_as_float(t6);
+    carry = carry + __int_as_float(t7);
+    asm volatile("" : "+v"(carry));
     return carry;
 }
-#undef GAMS_SEQ_STEP
 
-__device__ __noinline__ int exact_signal_wave(const uint8_t *K, uint32_t tj, uint32_t ti, uint32_t n,
-                                              float fsize, float thr) {
+// Sequential f32 sum of the first `m` lane values of `x` (m <= 64, wave-uniform) on top of
+// `carry`.  Lanes past m must hold +0.0f: the sums here are of non-negative terms and start at
+// +0.0f, so a padding term leaves them unchanged; whole groups of eight past m are skipped.
+// Out of line: one 0.8-KB body shared by the four calls of an evaluation.
+__device__ __noinline__ float seq_add_lanes(float carry, float x, uint32_t m) {
+    carry = seq_add8<0>(carry, x);
+    if (m > 8u) carry = seq_add8<8>(carry, x);
+    if (m > 16u) carry = seq_add8<16>(carry, x);
+    if (m > 24u) carry = seq_add8<24>(carry, x);
+    if (m > 32u) carry = seq_add8<32>(carry, x);
+    if (m > 40u) carry = seq_add8<40>(carry, x);
+    if (m > 48u) carry = seq_add8<48>(carry, x);
+    if (m > 56u) carry = seq_add8<56>(carry, x);
+    return carry;
+}
+
+// Inlined into the kernel, where K is known to be LDS (ds_read); behind a call boundary it is a
+// generic pointer and every count costs a flat load (~1k cycles per evaluation).  The
+// sequential part stays out of line (seq_add_lanes) and takes values, not pointers.
+__device__ __forceinline__ int exact_signal_wave(const uint8_t *K, uint32_t tj, uint32_t ti, uint32_t n,
+                                                 float fsize, float thr) {
     const uint32_t lane = threadIdx.x & 63u;
     const float len = (float)n;
     // lanes past the end contribute +0.0f, which leaves an f32 sum of non-negative terms unchanged

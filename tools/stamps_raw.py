@@ -57,3 +57,9 @@ for w in worst:
     print("  ", dur[w].tolist(), "total", int(tot[w]))
 ex = dur[:, 4]
 print("exact phase: median", int(np.median(ex)), "n>1000:", int((ex > 1000).sum()), "mean of those", int(ex[ex > 1000].mean()) if (ex > 1000).any() else 0)
+# the workgroups that finish last: when they started, their phases, whether a wave of theirs ran the exact path
+last = np.argsort(end)[-16:]
+print("last 16 workgroups to finish: entry us, end us, phase cycles")
+for w in last:
+    print(f"   entry {entry[w]:5.2f}  end {end[w]:5.2f}  phases {dur[w].tolist()}")
+print("end-time percentiles us", np.percentile(end, [50, 90, 95, 99, 100]).round(2))
