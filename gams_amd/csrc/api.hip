@@ -59,6 +59,13 @@ void gams_gpu_destroy(gams_gpu_t *h) {
         (void)hipStreamSynchronize(h->readback);
         (void)hipStreamDestroy(h->readback);
     }
+    for (int k = 0; k < gams_gpu::kMaxWays - 1; ++k) {
+        if (h->aux[k]) {
+            (void)hipStreamSynchronize(h->aux[k]);
+            (void)hipStreamDestroy(h->aux[k]);
+        }
+        if (h->aux_ev[k]) (void)hipEventDestroy(h->aux_ev[k]);
+    }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->k0) (void)hipEventDestroy(h->k0);
@@ -89,6 +96,8 @@ int gams_gpu_sync(gams_gpu_t *h) {
     GAMS_HIP(h, hipSetDevice(h->device));
     GAMS_HIP(h, hipStreamSynchronize(h->copy));
     GAMS_HIP(h, hipStreamSynchronize(h->compute));
+    for (int k = 0; k < gams_gpu::kMaxWays - 1; ++k)
+        if (h->aux[k]) GAMS_HIP(h, hipStreamSynchronize(h->aux[k]));
     GAMS_HIP(h, hipStreamSynchronize(h->readback));
     return GAMS_OK;
 }
@@ -103,6 +112,14 @@ int gams_gpu_timer_start(gams_gpu_t *h) {
 int gams_gpu_timer_stop(gams_gpu_t *h, float *ms) {
     if (!h || !ms) return gams_fail(h, GAMS_EINVAL, "timer_stop: null argument");
     GAMS_HIP(h, hipSetDevice(h->device));
+    // the timed region ends when every stream the plans run on has drained: the compute stream
+    // queues behind the auxiliary ones before the closing event
+    for (int k = 0; k < gams_gpu::kMaxWays - 1; ++k) {
+        if (!h->aux[k]) continue;
+        if (!h->aux_ev[k]) GAMS_HIP(h, hipEventCreateWithFlags(&h->aux_ev[k], hipEventDisableTiming));
+        GAMS_HIP(h, hipEventRecord(h->aux_ev[k], h->aux[k]));
+        GAMS_HIP(h, hipStreamWaitEvent(h->compute, h->aux_ev[k], 0));
+    }
     GAMS_HIP(h, hipEventRecord(h->ev1, h->compute));
     GAMS_HIP(h, hipEventSynchronize(h->ev1));
     GAMS_HIP(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
@@ -152,6 +169,7 @@ int gams_seqset_create(gams_gpu_t *h, uint32_t n_ctg, const uint32_t *lengths, g
     if (hipEventCreateWithFlags(&s->uploaded, hipEventDisableTiming) == hipSuccess &&
         hipEventRecord(s->uploaded, h->copy) == hipSuccess)
         s->dirty = true;
+    ++s->upload_gen;
     *out = s;
     return GAMS_OK;
 }
@@ -185,6 +203,7 @@ int gams_seqset_upload(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, const uint8_
     }
     GAMS_HIP(h, hipEventRecord(s->uploaded, h->copy));
     s->dirty = true;
+    ++s->upload_gen;
     return GAMS_OK;
 }
 
@@ -254,6 +273,7 @@ int gams_seqset_upload_all(gams_gpu_t *h, gams_seqset_t *s, const uint8_t *const
     }
     GAMS_HIP(h, hipEventRecord(s->uploaded, h->copy));
     s->dirty = true;
+    ++s->upload_gen;
     return GAMS_OK;
 }
 

@@ -16,6 +16,10 @@ struct gams_gpu {
     hipStream_t compute = nullptr;  // every kernel of the library runs here
     hipStream_t copy = nullptr;     // H2D staging of seq: bytes
     hipStream_t readback = nullptr; // packing + D2H of a finished run's results (waits on that run only)
+    // a wave plan of depth D rotates its runs over `compute` and aux[0..D-2] (gams_wave_plan_set_depth)
+    static constexpr int kMaxWays = 4;
+    hipStream_t aux[kMaxWays - 1] = {};
+    hipEvent_t aux_ev[kMaxWays - 1] = {};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t k0 = nullptr, k1 = nullptr;  // around the kernel of the last query-style call
     bool k_valid = false;
@@ -68,7 +72,8 @@ struct gams_seqset {
     size_t cap = 0;                 // size of the pooled block behind d_seq
     uint8_t *d_seq = nullptr;
     hipEvent_t uploaded = nullptr;    // recorded on the copy stream after the last upload; kernels wait on it
-    bool dirty = false;               // an upload happened since the last wait was queued
+    bool dirty = false;               // an upload happened since the last wait was queued (compute stream)
+    uint64_t upload_gen = 0;          // counts uploads; streams other than `compute` compare it with what they saw
     gams_gcindex *gcindex = nullptr;  // built lazily by gams_gpu_sw, dropped by every upload
 };
 

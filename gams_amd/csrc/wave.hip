@@ -1016,32 +1016,47 @@ struct gams_wave_plan {
     // device
     WaveCtgDev *d_ctgs = nullptr;
     WaveTile *d_tiles = nullptr;
-    gams_peak_t *d_peaks = nullptr;             // one slot of tile_cap records per tile (pooled block)
-    size_t d_peaks_bytes = 0, d_dense_bytes = 0;
+    // Outputs of one pass.  A plan of depth D owns D of these "ways"; consecutive gams_wave_run
+    // calls rotate over them, each way on its own HIP stream, so that independent passes overlap
+    // on the device (a 12-Mb pass alone is launch-latency bound).
+    struct Way {
+        gams_peak_t *d_peaks = nullptr;         // one slot of tile_cap records per tile (pooled block)
+        size_t d_peaks_bytes = 0;
+        uint32_t *d_tile_cnt = nullptr;         // inside arena_geom
+        unsigned long long *d_counters = nullptr;   // ring of kCounterRing slots, zeroed once per lap (pooled)
+        size_t d_counters_bytes = 0;
+        uint64_t runs = 0;                      // passes this way has run
+        uint32_t last_ring = 0;                 // ring slot of its last pass
+        uint32_t *d_dense_cnt = nullptr;        // --signal rows / input of the serial kernel (pooled)
+        int8_t *d_dense_sig = nullptr;
+        float *d_filtered = nullptr;
+        size_t d_dense_cnt_bytes = 0, d_dense_sig_bytes = 0, d_filtered_bytes = 0;
+        hipEvent_t done = nullptr;              // pipelined mode: recorded behind each run's kernels
+        hipEvent_t ran_ev = nullptr;            // lets the readback stream queue behind the last run
+        uint64_t seen_upload = 0;               // seqset upload generation this way's stream has waited for
+        bool seen_ready = false;                // ... and the plan's const table
+    };
+    Way way[gams_gpu::kMaxWays];
+    uint32_t depth = 1;                         // ways in use
+    uint32_t last_way = 0;                      // way of the most recent run
+    uint32_t sel_age = 0;                       // readers look at the run `sel_age` before the most recent one
+    hipEvent_t ready = nullptr;                 // recorded on the compute stream behind the const table
+    size_t d_dense_bytes = 0;
     gams_peak_t *h_peaks = nullptr;             // pinned: packed peaks of the last gams_wave_peaks
     size_t h_peaks_bytes = 0;
     uint32_t tile_cap = 0, tile_cap_req = 0;
     gams_peak_t *d_dense = nullptr;             // packed copy made by gams_wave_peaks
     uint64_t dense_cap = 0;
-    unsigned long long *d_counters = nullptr;   // ring of kCounterRing slots x 4 words, zeroed once per lap
     uint64_t run_idx = 0;
-    uint32_t last_slot = 0;
     int8_t *d_const_sig = nullptr;              // [size+1], see wave_const_table_kernel
     unsigned long long *d_stamps = nullptr;     // diagnostics, [tiles][8]
     unsigned long long *d_tile_off = nullptr;
-    uint32_t *d_tile_cnt = nullptr;
-    // two pooled arenas hold the small tables: `fixed` = ctgs | counters | const_sig (life of the
-    // plan), `geom` = tiles | tile_off (+2 totals) | tile_cnt (replaced when the tiling changes)
+    // two pooled arenas hold the small tables: `fixed` = ctgs | const_sig (life of the plan),
+    // `geom` = tiles | tile_off (+2 totals) | tile_cnt per way (replaced when the tiling changes)
     uint8_t *arena_fixed = nullptr, *arena_geom = nullptr;
     size_t arena_fixed_bytes = 0, arena_geom_bytes = 0;
-    uint32_t *d_dense_cnt = nullptr;
-    int8_t *d_dense_sig = nullptr;
-    float *d_filtered = nullptr;
-    // host results
-    hipEvent_t ran_ev = nullptr;                // lets the readback stream queue behind the last run
     bool ran = false;
-    hipEvent_t done = nullptr;    // pipelined mode: recorded behind each run's kernels, readers wait on it
-    bool pipelined = false;       // gams_wave_plan_set_pipelined: off = readers synchronise the compute stream
+    bool pipelined = false;       // gams_wave_plan_set_pipelined: an event per run; readers wait on it
     bool attr_set = false;        // dynamic-LDS attribute applied for the current geometry
     float g0 = 0, g1 = 0, g2 = 0, g3 = 0;
 };
@@ -1173,32 +1188,52 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
 
 inline size_t wave_align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// the stream way k runs on: the handle's compute stream, or one of its auxiliary streams
+hipStream_t wave_stream(gams_gpu_t *h, uint32_t k) { return k == 0 ? h->compute : h->aux[k - 1]; }
+
+// the way the readers look at
+gams_wave_plan::Way &wave_read_way(gams_wave_plan_t *p) {
+    return p->way[(p->last_way + p->depth - (p->sel_age % p->depth)) % p->depth];
+}
+uint32_t wave_read_way_index(const gams_wave_plan_t *p) {
+    return (p->last_way + p->depth - (p->sel_age % p->depth)) % p->depth;
+}
+
+int wave_sync_ways(gams_gpu_t *h, gams_wave_plan_t *p) {
+    for (uint32_t k = 0; k < p->depth; ++k) GAMS_HIP(h, hipStreamSynchronize(wave_stream(h, k)));
+    return GAMS_OK;
+}
+
 int wave_upload_geometry(gams_gpu_t *h, gams_wave_plan_t *p) {
     gams_pool_free(h, false, p->arena_geom, p->arena_geom_bytes);
     p->arena_geom = nullptr;
     p->d_tiles = nullptr;
     p->d_tile_off = nullptr;
-    p->d_tile_cnt = nullptr;
     const size_t nt = std::max<size_t>(p->tiles.size(), 1);
     const size_t b_tiles = wave_align256(nt * sizeof(WaveTile));
     const size_t b_off = wave_align256((nt + 2) * sizeof(unsigned long long));   // + the two totals
     const size_t b_cnt = wave_align256(nt * sizeof(uint32_t));
-    GAMS_HIP(h, gams_pool_alloc(h, false, b_tiles + b_off + b_cnt, reinterpret_cast<void **>(&p->arena_geom),
-                                &p->arena_geom_bytes));
+    for (auto &w : p->way) w.d_tile_cnt = nullptr;
+    GAMS_HIP(h, gams_pool_alloc(h, false, b_tiles + b_off + b_cnt * p->depth,
+                                reinterpret_cast<void **>(&p->arena_geom), &p->arena_geom_bytes));
     p->d_tiles = reinterpret_cast<WaveTile *>(p->arena_geom);
     p->d_tile_off = reinterpret_cast<unsigned long long *>(p->arena_geom + b_tiles);
-    p->d_tile_cnt = reinterpret_cast<uint32_t *>(p->arena_geom + b_tiles + b_off);
+    for (uint32_t k = 0; k < p->depth; ++k)
+        p->way[k].d_tile_cnt = reinterpret_cast<uint32_t *>(p->arena_geom + b_tiles + b_off + b_cnt * k);
     if (p->flags & GAMS_WAVE_PEAKS) {
         // a slot of tw/8 records per tile (typical density is 1-2 % of the windows); a tile that
         // overflows makes gams_wave_peaks() regrow the slots to tw records and run again
-        gams_pool_free(h, false, p->d_peaks, p->d_peaks_bytes);
         gams_pool_free(h, false, p->d_dense, p->d_dense_bytes);
-        p->d_peaks = nullptr;
         p->d_dense = nullptr;
         p->dense_cap = 0;
         p->tile_cap = std::max<uint32_t>(p->tile_cap_req ? p->tile_cap_req : p->tw / 8u, 16u);
-        GAMS_HIP(h, gams_pool_alloc(h, false, nt * (size_t)p->tile_cap * sizeof(gams_peak_t),
-                                    reinterpret_cast<void **>(&p->d_peaks), &p->d_peaks_bytes));
+        for (auto &w : p->way) {
+            gams_pool_free(h, false, w.d_peaks, w.d_peaks_bytes);
+            w.d_peaks = nullptr;
+        }
+        for (uint32_t k = 0; k < p->depth; ++k)
+            GAMS_HIP(h, gams_pool_alloc(h, false, nt * (size_t)p->tile_cap * sizeof(gams_peak_t),
+                                        reinterpret_cast<void **>(&p->way[k].d_peaks), &p->way[k].d_peaks_bytes));
     }
     if (!p->tiles.empty())
         GAMS_HIP(h, hipMemcpy(p->d_tiles, p->tiles.data(), p->tiles.size() * sizeof(WaveTile),
@@ -1206,28 +1241,55 @@ int wave_upload_geometry(gams_gpu_t *h, gams_wave_plan_t *p) {
     return GAMS_OK;
 }
 
+// per-way buffers that do not depend on the tiling: counter ring, dense rows, filtered[]
+int wave_alloc_ways(gams_gpu_t *h, gams_wave_plan_t *p) {
+    const uint64_t base = std::max<uint64_t>(p->total_windows, 1);
+    const bool need_dense = (p->flags & GAMS_WAVE_DENSE) || p->serial;
+    for (uint32_t k = 0; k < p->depth; ++k) {
+        gams_wave_plan::Way &w = p->way[k];
+        if (!w.d_counters) {
+            GAMS_HIP(h, gams_pool_alloc(h, false, kCounterRing * kSlotWords * sizeof(unsigned long long),
+                                        reinterpret_cast<void **>(&w.d_counters), &w.d_counters_bytes));
+            // queued in front of the way's first run on its own stream
+            GAMS_HIP(h, hipMemsetAsync(w.d_counters, 0, kCounterRing * kSlotWords * sizeof(unsigned long long),
+                                       wave_stream(h, k)));
+            w.runs = 0;
+        }
+        if (need_dense && !w.d_dense_cnt) {
+            GAMS_HIP(h, gams_pool_alloc(h, false, base * sizeof(uint32_t), reinterpret_cast<void **>(&w.d_dense_cnt),
+                                        &w.d_dense_cnt_bytes));
+            GAMS_HIP(h, gams_pool_alloc(h, false, base, reinterpret_cast<void **>(&w.d_dense_sig),
+                                        &w.d_dense_sig_bytes));
+        }
+        if (p->serial && !w.d_filtered)
+            GAMS_HIP(h, gams_pool_alloc(h, false, base * sizeof(float), reinterpret_cast<void **>(&w.d_filtered),
+                                        &w.d_filtered_bytes));
+    }
+    return GAMS_OK;
+}
+
 template <typename KT, bool WIDE>
-int wave_launch(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a) {
+int wave_launch(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a, hipStream_t st) {
     auto kern = wave_tile_kernel<KT, WIDE>;
     if (!p->attr_set) {
         GAMS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
         p->attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)p->tiles.size()), dim3(256), p->lds_bytes, h->compute, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)p->tiles.size()), dim3(256), p->lds_bytes, st, a);
     GAMS_HIP(h, hipGetLastError());
     return GAMS_OK;
 }
 
 template <int W, int SIZE, int STEP, int LAG>
-int wave_launch_fast(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a) {
+int wave_launch_fast(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a, hipStream_t st) {
     auto kern = wave_fast_kernel<W, SIZE, STEP, LAG>;
     if (!p->attr_set) {
         GAMS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
         p->attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)p->tiles.size()), dim3(256), p->lds_bytes, h->compute, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)p->tiles.size()), dim3(256), p->lds_bytes, st, a);
     GAMS_HIP(h, hipGetLastError());
     return GAMS_OK;
 }
@@ -1299,29 +1361,24 @@ int gams_wave_plan_create(gams_gpu_t *h, gams_seqset_t *s, const gams_wave_param
     } while (0)
     {
         const size_t b_ctgs = wave_align256(std::max<size_t>(s->n_ctg, 1) * sizeof(WaveCtgDev));
-        const size_t b_counters = wave_align256(kCounterRing * kSlotWords * sizeof(unsigned long long));
         const size_t b_const = wave_align256((size_t)params->size + 1);
-        PLAN_HIP(gams_pool_alloc(h, false, b_ctgs + b_counters + b_const, reinterpret_cast<void **>(&p->arena_fixed),
+        PLAN_HIP(gams_pool_alloc(h, false, b_ctgs + b_const, reinterpret_cast<void **>(&p->arena_fixed),
                                  &p->arena_fixed_bytes));
         p->d_ctgs = reinterpret_cast<WaveCtgDev *>(p->arena_fixed);
-        p->d_counters = reinterpret_cast<unsigned long long *>(p->arena_fixed + b_ctgs);
-        p->d_const_sig = reinterpret_cast<int8_t *>(p->arena_fixed + b_ctgs + b_counters);
+        p->d_const_sig = reinterpret_cast<int8_t *>(p->arena_fixed + b_ctgs);
     }
     if (s->n_ctg)
         PLAN_HIP(hipMemcpy(p->d_ctgs, p->ctgs.data(), s->n_ctg * sizeof(WaveCtgDev), hipMemcpyHostToDevice));
     rc = wave_upload_geometry(h, p);
     if (rc != GAMS_OK) return fail(rc);
-    // queued in front of the first run on the same stream
-    PLAN_HIP(hipMemsetAsync(p->d_counters, 0, kCounterRing * kSlotWords * sizeof(unsigned long long), h->compute));
+    rc = wave_alloc_ways(h, p);
+    if (rc != GAMS_OK) return fail(rc);
     hipLaunchKernelGGL(wave_const_table_kernel, dim3((params->size + 256) / 256), dim3(256), 0, h->compute,
                        p->d_const_sig, (uint32_t)params->size, params->lag, params->threshold);
     PLAN_HIP(hipGetLastError());
-    const bool need_dense = (flags & GAMS_WAVE_DENSE) || p->serial;
-    if (need_dense) {
-        PLAN_HIP(hipMalloc(&p->d_dense_cnt, std::max<uint64_t>(base, 1) * sizeof(uint32_t)));
-        PLAN_HIP(hipMalloc(&p->d_dense_sig, std::max<uint64_t>(base, 1)));
-    }
-    if (p->serial) PLAN_HIP(hipMalloc(&p->d_filtered, std::max<uint64_t>(base, 1) * sizeof(float)));
+    PLAN_HIP(hipEventCreateWithFlags(&p->ready, hipEventDisableTiming));
+    PLAN_HIP(hipEventRecord(p->ready, h->compute));
+    p->way[0].seen_ready = true;   // same stream
 #undef PLAN_HIP
     *out = p;
     return GAMS_OK;
@@ -1329,20 +1386,27 @@ int gams_wave_plan_create(gams_gpu_t *h, gams_seqset_t *s, const gams_wave_param
 
 void gams_wave_plan_destroy(gams_gpu_t *h, gams_wave_plan_t *p) {
     if (!p) return;
-    if (h) (void)hipSetDevice(h->device);
-    if (h && h->compute) (void)hipStreamSynchronize(h->compute);
+    if (h) {
+        (void)hipSetDevice(h->device);
+        for (uint32_t k = 0; k < p->depth; ++k)
+            if (wave_stream(h, k)) (void)hipStreamSynchronize(wave_stream(h, k));
+        if (h->readback) (void)hipStreamSynchronize(h->readback);
+    }
     gams_pool_free(h, false, p->arena_fixed, p->arena_fixed_bytes);
     gams_pool_free(h, false, p->arena_geom, p->arena_geom_bytes);
-    if (h && h->readback) (void)hipStreamSynchronize(h->readback);
-    gams_pool_free(h, false, p->d_peaks, p->d_peaks_bytes);
     gams_pool_free(h, false, p->d_dense, p->d_dense_bytes);
     gams_pool_free(h, true, p->h_peaks, p->h_peaks_bytes);
-    if (p->done) (void)hipEventDestroy(p->done);
-    if (p->ran_ev) (void)hipEventDestroy(p->ran_ev);
+    for (auto &w : p->way) {
+        gams_pool_free(h, false, w.d_peaks, w.d_peaks_bytes);
+        gams_pool_free(h, false, w.d_counters, w.d_counters_bytes);
+        gams_pool_free(h, false, w.d_dense_cnt, w.d_dense_cnt_bytes);
+        gams_pool_free(h, false, w.d_dense_sig, w.d_dense_sig_bytes);
+        gams_pool_free(h, false, w.d_filtered, w.d_filtered_bytes);
+        if (w.done) (void)hipEventDestroy(w.done);
+        if (w.ran_ev) (void)hipEventDestroy(w.ran_ev);
+    }
+    if (p->ready) (void)hipEventDestroy(p->ready);
     (void)hipFree(p->d_stamps);
-    (void)hipFree(p->d_dense_cnt);
-    (void)hipFree(p->d_dense_sig);
-    (void)hipFree(p->d_filtered);
     delete p;
 }
 
@@ -1355,8 +1419,9 @@ uint32_t gams_wave_ctg_windows(const gams_wave_plan_t *p, uint32_t i) {
 int gams_wave_plan_set_tile(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tile_windows) {
     if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_plan_set_tile: null argument");
     GAMS_HIP(h, hipSetDevice(h->device));
-    GAMS_HIP(h, hipStreamSynchronize(h->compute));
-    int rc = wave_build_geometry(h, p, tile_windows);
+    int rc = wave_sync_ways(h, p);
+    if (rc != GAMS_OK) return rc;
+    rc = wave_build_geometry(h, p, tile_windows);
     if (rc != GAMS_OK) return rc;
     p->ran = false;
     (void)hipFree(p->d_stamps);
@@ -1367,18 +1432,33 @@ int gams_wave_plan_set_tile(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tile_wi
 int gams_wave_run(gams_gpu_t *h, gams_wave_plan_t *p) {
     if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_run: null argument");
     GAMS_HIP(h, hipSetDevice(h->device));
-    int wrc = gams_seqset_wait_uploads(h, p->set);   // stream-side wait: uploads queued on the copy stream
-    if (wrc != GAMS_OK) return wrc;
-    const uint32_t slot = (uint32_t)(p->run_idx % kCounterRing);
-    if (slot == 0 && p->run_idx > 0)
-        GAMS_HIP(h, hipMemsetAsync(p->d_counters, 0, kCounterRing * kSlotWords * sizeof(unsigned long long),
-                                   h->compute));
+    const uint32_t k = (uint32_t)(p->run_idx % p->depth);
+    gams_wave_plan::Way &w = p->way[k];
+    hipStream_t st = wave_stream(h, k);
+    // inputs: the way's stream queues behind the uploads and the plan's const table (no host wait)
+    if (k == 0) {
+        int wrc = gams_seqset_wait_uploads(h, p->set);
+        if (wrc != GAMS_OK) return wrc;
+    } else if (w.seen_upload != p->set->upload_gen && p->set->uploaded) {
+        GAMS_HIP(h, hipStreamWaitEvent(st, p->set->uploaded, 0));
+    }
+    w.seen_upload = p->set->upload_gen;
+    if (!w.seen_ready) {
+        GAMS_HIP(h, hipStreamWaitEvent(st, p->ready, 0));
+        w.seen_ready = true;
+    }
+    const uint32_t slot = (uint32_t)(w.runs % kCounterRing);
+    if (slot == 0 && w.runs > 0)
+        GAMS_HIP(h, hipMemsetAsync(w.d_counters, 0, kCounterRing * kSlotWords * sizeof(unsigned long long), st));
+    ++w.runs;
     ++p->run_idx;
-    p->last_slot = slot;
+    w.last_ring = slot;
+    p->last_way = k;
+    p->sel_age = 0;
     p->ran = true;
-    if (p->pipelined && !p->done) GAMS_HIP(h, hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
+    if (p->pipelined && !w.done) GAMS_HIP(h, hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
     if (p->tiles.empty()) {
-        if (p->pipelined) GAMS_HIP(h, hipEventRecord(p->done, h->compute));
+        if (p->pipelined) GAMS_HIP(h, hipEventRecord(w.done, st));
         return GAMS_OK;
     }
     const gams_wave_params_t &q = p->prm;
@@ -1403,61 +1483,95 @@ int gams_wave_run(gams_gpu_t *h, gams_wave_plan_t *p) {
     a.g1 = p->g1;
     a.g2 = p->g2;
     a.g3 = p->g3;
-    a.peaks = p->d_peaks;
+    a.peaks = w.d_peaks;
     a.tile_cap = p->tile_cap;
-    a.counters = p->d_counters + kSlotWords * slot;
+    a.counters = w.d_counters + kSlotWords * slot;
     a.const_sig = p->d_const_sig;
     a.stamps = p->d_stamps;
-    a.tile_cnt = p->d_tile_cnt;
-    a.dense_cnt = p->d_dense_cnt;
-    a.dense_sig = p->d_dense_sig;
+    a.tile_cnt = w.d_tile_cnt;
+    a.dense_cnt = w.d_dense_cnt;
+    a.dense_sig = w.d_dense_sig;
     int rc;
     const bool headline = q.size == 100 && q.step == 10 && q.lag == 100;   // every BASELINE step-10 config
     const bool step1 = q.size == 100 && q.step == 1 && q.lag == 100;       // BASELINE configs[3] (GRCh38, step 1)
     if (p->fast_w == 20)
-        rc = step1 ? wave_launch_fast<20, 100, 1, 100>(h, p, a) : wave_launch_fast<20, 0, 0, 0>(h, p, a);
+        rc = step1 ? wave_launch_fast<20, 100, 1, 100>(h, p, a, st) : wave_launch_fast<20, 0, 0, 0>(h, p, a, st);
     else if (p->fast_w == 12)
-        rc = headline ? wave_launch_fast<12, 100, 10, 100>(h, p, a)
-             : step1  ? wave_launch_fast<12, 100, 1, 100>(h, p, a)
-                      : wave_launch_fast<12, 0, 0, 0>(h, p, a);
+        rc = headline ? wave_launch_fast<12, 100, 10, 100>(h, p, a, st)
+             : step1  ? wave_launch_fast<12, 100, 1, 100>(h, p, a, st)
+                      : wave_launch_fast<12, 0, 0, 0>(h, p, a, st);
     else if (p->fast_w == 4)
-        rc = headline ? wave_launch_fast<4, 100, 10, 100>(h, p, a) : wave_launch_fast<4, 0, 0, 0>(h, p, a);
+        rc = headline ? wave_launch_fast<4, 100, 10, 100>(h, p, a, st) : wave_launch_fast<4, 0, 0, 0>(h, p, a, st);
     else if (p->k16)
-        rc = p->wide ? wave_launch<uint16_t, true>(h, p, a) : wave_launch<uint16_t, false>(h, p, a);
+        rc = p->wide ? wave_launch<uint16_t, true>(h, p, a, st) : wave_launch<uint16_t, false>(h, p, a, st);
     else
-        rc = p->wide ? wave_launch<uint8_t, true>(h, p, a) : wave_launch<uint8_t, false>(h, p, a);
+        rc = p->wide ? wave_launch<uint8_t, true>(h, p, a, st) : wave_launch<uint8_t, false>(h, p, a, st);
     if (rc != GAMS_OK) return rc;
     if (p->serial) {
         const uint32_t n = p->set->n_ctg;
-        hipLaunchKernelGGL(wave_serial_kernel, dim3((n + 63) / 64), dim3(64), 0, h->compute, p->d_ctgs, n,
-                           p->d_dense_cnt, p->d_dense_sig, p->d_filtered, q.lag, q.threshold, q.influence,
-                           (float)q.size);
+        hipLaunchKernelGGL(wave_serial_kernel, dim3((n + 63) / 64), dim3(64), 0, st, p->d_ctgs, n, w.d_dense_cnt,
+                           w.d_dense_sig, w.d_filtered, q.lag, q.threshold, q.influence, (float)q.size);
         GAMS_HIP(h, hipGetLastError());
         if (p->flags & GAMS_WAVE_PEAKS) {
-            hipLaunchKernelGGL(wave_compact_kernel, dim3((unsigned)p->tiles.size()), dim3(256), 0, h->compute,
-                               p->d_ctgs, p->d_tiles, p->tw, p->d_dense_cnt, p->d_dense_sig, p->d_peaks,
-                               p->tile_cap, p->d_tile_cnt);
+            hipLaunchKernelGGL(wave_compact_kernel, dim3((unsigned)p->tiles.size()), dim3(256), 0, st, p->d_ctgs,
+                               p->d_tiles, p->tw, w.d_dense_cnt, w.d_dense_sig, w.d_peaks, p->tile_cap, w.d_tile_cnt);
             GAMS_HIP(h, hipGetLastError());
         }
     }
     // An event per run costs a marker packet between back-to-back launches (measured: 8.8 ->
     // 11.7 us per 12-Mb pass), so it is only recorded for plans that overlap several runs.
-    if (p->pipelined) GAMS_HIP(h, hipEventRecord(p->done, h->compute));
+    if (p->pipelined) GAMS_HIP(h, hipEventRecord(w.done, st));
     return GAMS_OK;
 }
 
-// wait for the plan's last run: its own event in pipelined mode, else the whole compute stream
+// wait for the run the readers look at: its own event in pipelined mode, else its whole stream
 static int wave_wait_last_run(gams_gpu_t *h, gams_wave_plan_t *p) {
-    if (p->pipelined && p->done)
-        GAMS_HIP(h, hipEventSynchronize(p->done));
+    gams_wave_plan::Way &w = wave_read_way(p);
+    if (p->pipelined && w.done)
+        GAMS_HIP(h, hipEventSynchronize(w.done));
     else
-        GAMS_HIP(h, hipStreamSynchronize(h->compute));
+        GAMS_HIP(h, hipStreamSynchronize(wave_stream(h, wave_read_way_index(p))));
     return GAMS_OK;
 }
 
 int gams_wave_plan_set_pipelined(gams_gpu_t *h, gams_wave_plan_t *p, int enable) {
     if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_plan_set_pipelined: null argument");
     p->pipelined = enable != 0;
+    return GAMS_OK;
+}
+
+int gams_wave_run_n(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t n) {
+    for (uint32_t i = 0; i < n; ++i) {
+        int rc = gams_wave_run(h, p);
+        if (rc != GAMS_OK) return rc;
+    }
+    return GAMS_OK;
+}
+
+int gams_wave_plan_set_depth(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t depth) {
+    if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_plan_set_depth: null argument");
+    if (depth < 1 || depth > (uint32_t)gams_gpu::kMaxWays)
+        return gams_fail(h, GAMS_EINVAL, "wave_plan_set_depth: depth must be 1.." + std::to_string(gams_gpu::kMaxWays));
+    GAMS_HIP(h, hipSetDevice(h->device));
+    int rc = wave_sync_ways(h, p);
+    if (rc != GAMS_OK) return rc;
+    for (uint32_t k = 1; k < depth; ++k)
+        if (!h->aux[k - 1]) GAMS_HIP(h, hipStreamCreateWithFlags(&h->aux[k - 1], hipStreamNonBlocking));
+    p->depth = depth;
+    p->ran = false;
+    p->run_idx = 0;
+    p->last_way = 0;
+    p->sel_age = 0;
+    rc = wave_upload_geometry(h, p);
+    if (rc == GAMS_OK) rc = wave_alloc_ways(h, p);
+    return rc;
+}
+
+int gams_wave_plan_select(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t age) {
+    if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_plan_select: null argument");
+    if (age >= p->depth || age >= p->run_idx)
+        return gams_fail(h, GAMS_ESTATE, "wave_plan_select: that run is no longer (or not yet) held");
+    p->sel_age = age;
     return GAMS_OK;
 }
 
@@ -1472,16 +1586,18 @@ int gams_wave_peaks(gams_gpu_t *h, gams_wave_plan_t *p, const gams_peak_t **peak
         *n_peaks = 0;
         return GAMS_OK;
     }
-    unsigned long long *const d_totals = p->d_tile_off + nt;          // two words behind the offsets
     for (int attempt = 0; attempt < 2; ++attempt) {
+        // two words behind the offsets (re-read every attempt: a regrow replaces the arena)
+        unsigned long long *const d_totals = p->d_tile_off + nt;
         // The readback stream queues behind the run (pipelined: behind this plan's run only, later
         // runs of other plans keep going); the host waits once, for the two totals.
-        if (p->pipelined && p->done) {
-            GAMS_HIP(h, hipStreamWaitEvent(h->readback, p->done, 0));
+        gams_wave_plan::Way &w = wave_read_way(p);
+        if (p->pipelined && w.done) {
+            GAMS_HIP(h, hipStreamWaitEvent(h->readback, w.done, 0));
         } else {
-            if (!p->ran_ev) GAMS_HIP(h, hipEventCreateWithFlags(&p->ran_ev, hipEventDisableTiming));
-            GAMS_HIP(h, hipEventRecord(p->ran_ev, h->compute));
-            GAMS_HIP(h, hipStreamWaitEvent(h->readback, p->ran_ev, 0));
+            if (!w.ran_ev) GAMS_HIP(h, hipEventCreateWithFlags(&w.ran_ev, hipEventDisableTiming));
+            GAMS_HIP(h, hipEventRecord(w.ran_ev, wave_stream(h, wave_read_way_index(p))));
+            GAMS_HIP(h, hipStreamWaitEvent(h->readback, w.ran_ev, 0));
         }
         if (!p->d_dense) {
             // typical density is 1-3 % of the windows; a fuller result regrows below
@@ -1490,11 +1606,11 @@ int gams_wave_peaks(gams_gpu_t *h, gams_wave_plan_t *p, const gams_peak_t **peak
                                         reinterpret_cast<void **>(&p->d_dense), &p->d_dense_bytes));
             p->dense_cap = p->d_dense_bytes / sizeof(gams_peak_t);
         }
-        hipLaunchKernelGGL(wave_offsets_kernel, dim3(1), dim3(1024), 0, h->readback, p->d_tile_cnt, (uint32_t)nt,
+        hipLaunchKernelGGL(wave_offsets_kernel, dim3(1), dim3(1024), 0, h->readback, w.d_tile_cnt, (uint32_t)nt,
                            p->d_tile_off, d_totals);
         GAMS_HIP(h, hipGetLastError());
-        hipLaunchKernelGGL(wave_gather_kernel, dim3((unsigned)nt), dim3(64), 0, h->readback, p->d_peaks,
-                           p->tile_cap, p->d_tile_cnt, p->d_tile_off, p->d_dense, (unsigned long long)p->dense_cap);
+        hipLaunchKernelGGL(wave_gather_kernel, dim3((unsigned)nt), dim3(64), 0, h->readback, w.d_peaks,
+                           p->tile_cap, w.d_tile_cnt, p->d_tile_off, p->d_dense, (unsigned long long)p->dense_cap);
         GAMS_HIP(h, hipGetLastError());
         GAMS_HIP(h, hipMemcpyAsync(h->pin_scratch, d_totals, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                                    h->readback));
@@ -1504,9 +1620,14 @@ int gams_wave_peaks(gams_gpu_t *h, gams_wave_plan_t *p, const gams_peak_t **peak
         if (worst > p->tile_cap) {
             // some tile signalled more windows than its slot holds: give every tile a slot of
             // tw records (the maximum possible) and run again
+            // (earlier runs still held by other ways are dropped with the old slots)
             p->tile_cap_req = p->tw;
-            int rc = wave_upload_geometry(h, p);
-            if (rc == GAMS_OK) rc = gams_wave_run(h, p);
+            int rc = wave_sync_ways(h, p);
+            if (rc == GAMS_OK) rc = wave_upload_geometry(h, p);
+            if (rc == GAMS_OK) {
+                p->run_idx = 0;
+                rc = gams_wave_run(h, p);
+            }
             if (rc != GAMS_OK) return rc;
             continue;
         }
@@ -1519,8 +1640,8 @@ int gams_wave_peaks(gams_gpu_t *h, gams_wave_plan_t *p, const gams_peak_t **peak
                 GAMS_HIP(h, gams_pool_alloc(h, false, want * sizeof(gams_peak_t),
                                             reinterpret_cast<void **>(&p->d_dense), &p->d_dense_bytes));
                 p->dense_cap = p->d_dense_bytes / sizeof(gams_peak_t);
-                hipLaunchKernelGGL(wave_gather_kernel, dim3((unsigned)nt), dim3(64), 0, h->readback, p->d_peaks,
-                                   p->tile_cap, p->d_tile_cnt, p->d_tile_off, p->d_dense,
+                hipLaunchKernelGGL(wave_gather_kernel, dim3((unsigned)nt), dim3(64), 0, h->readback, w.d_peaks,
+                                   p->tile_cap, w.d_tile_cnt, p->d_tile_off, p->d_dense,
                                    (unsigned long long)p->dense_cap);
                 GAMS_HIP(h, hipGetLastError());
             }
@@ -1554,18 +1675,22 @@ int gams_wave_dense(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t i, uint32_t *gc
     }
     const WaveCtgDev &c = p->ctgs[i];
     if (c.n_win == 0) return GAMS_OK;
+    gams_wave_plan::Way &w = wave_read_way(p);
     if (gc_count)
-        GAMS_HIP(h, hipMemcpy(gc_count, p->d_dense_cnt + c.win_base, (size_t)c.n_win * sizeof(uint32_t),
+        GAMS_HIP(h, hipMemcpy(gc_count, w.d_dense_cnt + c.win_base, (size_t)c.n_win * sizeof(uint32_t),
                               hipMemcpyDeviceToHost));
     if (signal)
-        GAMS_HIP(h, hipMemcpy(signal, p->d_dense_sig + c.win_base, (size_t)c.n_win, hipMemcpyDeviceToHost));
+        GAMS_HIP(h, hipMemcpy(signal, w.d_dense_sig + c.win_base, (size_t)c.n_win, hipMemcpyDeviceToHost));
     return GAMS_OK;
 }
 
 int gams_wave_plan_set_stamps(gams_gpu_t *h, gams_wave_plan_t *p, int enable) {
     if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_plan_set_stamps: null argument");
     GAMS_HIP(h, hipSetDevice(h->device));
-    GAMS_HIP(h, hipStreamSynchronize(h->compute));
+    {
+        int src = wave_sync_ways(h, p);
+        if (src != GAMS_OK) return src;
+    }
     (void)hipFree(p->d_stamps);
     p->d_stamps = nullptr;
     if (enable) {
@@ -1581,7 +1706,10 @@ int gams_wave_stamps(gams_gpu_t *h, gams_wave_plan_t *p, double *mean_cycles, ui
     if (!h || !p || !mean_cycles || !span_cycles) return gams_fail(h, GAMS_EINVAL, "wave_stamps: null argument");
     if (!p->d_stamps) return gams_fail(h, GAMS_ESTATE, "wave_stamps: stamps are off");
     GAMS_HIP(h, hipSetDevice(h->device));
-    GAMS_HIP(h, hipStreamSynchronize(h->compute));
+    {
+        int src = wave_sync_ways(h, p);
+        if (src != GAMS_OK) return src;
+    }
     const size_t nt = p->tiles.size();
     std::vector<unsigned long long> st(std::max<size_t>(nt, 1) * 16);
     GAMS_HIP(h, hipMemcpy(st.data(), p->d_stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1615,7 +1743,10 @@ int gams_wave_stamps_raw(gams_gpu_t *h, gams_wave_plan_t *p, uint64_t *out, uint
     if (!h || !p || !out) return gams_fail(h, GAMS_EINVAL, "wave_stamps_raw: null argument");
     if (!p->d_stamps) return gams_fail(h, GAMS_ESTATE, "wave_stamps_raw: stamps are off");
     GAMS_HIP(h, hipSetDevice(h->device));
-    GAMS_HIP(h, hipStreamSynchronize(h->compute));
+    {
+        int src = wave_sync_ways(h, p);
+        if (src != GAMS_OK) return src;
+    }
     const uint64_t n = std::min<uint64_t>(n_words, (uint64_t)p->tiles.size() * 16);
     GAMS_HIP(h, hipMemcpy(out, p->d_stamps, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return GAMS_OK;
@@ -1624,9 +1755,10 @@ int gams_wave_stamps_raw(gams_gpu_t *h, gams_wave_plan_t *p, uint64_t *out, uint
 int gams_wave_exact_count(gams_gpu_t *h, gams_wave_plan_t *p, uint64_t *n_exact) {
     if (!h || !p || !n_exact) return gams_fail(h, GAMS_EINVAL, "wave_exact_count: null argument");
     GAMS_HIP(h, hipSetDevice(h->device));
-    GAMS_HIP(h, hipStreamSynchronize(h->compute));
+    gams_wave_plan::Way &w = wave_read_way(p);
+    GAMS_HIP(h, hipStreamSynchronize(wave_stream(h, wave_read_way_index(p))));
     std::vector<unsigned long long> cnt(kSlotWords);
-    GAMS_HIP(h, hipMemcpy(cnt.data(), p->d_counters + kSlotWords * p->last_slot,
+    GAMS_HIP(h, hipMemcpy(cnt.data(), w.d_counters + kSlotWords * w.last_ring,
                           kSlotWords * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     uint64_t tot = 0;
     for (uint32_t sh = 0; sh < kShards; ++sh) tot += cnt[sh * kShardWords + 1];

@@ -128,6 +128,17 @@ class WavePlan:
     def ctg_windows(self, i):
         return self.eng.lib.gams_wave_ctg_windows(self.p, i)
 
+    def set_depth(self, depth):
+        """passes in flight: consecutive run() calls rotate over `depth` streams and output sets"""
+        self.eng.check(self.eng.lib.gams_wave_plan_set_depth(self.eng.h, self.p, depth))
+
+    def select(self, age):
+        """point peaks()/dense()/exact_count() at the run `age` runs before the most recent one"""
+        self.eng.check(self.eng.lib.gams_wave_plan_select(self.eng.h, self.p, age))
+
+    def run_n(self, n):
+        self.eng.check(self.eng.lib.gams_wave_run_n(self.eng.h, self.p, n))
+
     def run(self):
         self.eng.check(self.eng.lib.gams_wave_run(self.eng.h, self.p))
 

@@ -112,6 +112,17 @@ uint64_t gams_wave_total_windows(const gams_wave_plan_t *p);
 uint32_t gams_wave_ctg_windows(const gams_wave_plan_t *p, uint32_t i);
 /* One pass: queue the kernels on the compute stream (asynchronous). */
 int gams_wave_run(gams_gpu_t *h, gams_wave_plan_t *p);
+/* n passes queued back to back (the loop a host would write, without its per-call overhead) */
+int gams_wave_run_n(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t n);
+/* Passes in flight.  With depth D (1..4, default 1) consecutive gams_wave_run calls of the plan
+ * rotate over D HIP streams and D sets of output buffers, so that independent passes (batch
+ * after batch of ctgs, wave.rs:288-299 hands them to workers the same way) overlap on the device:
+ * a 12-Mb pass alone is launch-latency bound (8.2 us; 3.3 us each at depth 4).  The readers
+ * (gams_wave_peaks, gams_wave_dense, gams_wave_exact_count) return the most recent run;
+ * gams_wave_plan_select(age) points them at the run `age` runs earlier (age < depth).
+ * Changing the depth drops the results held so far. */
+int gams_wave_plan_set_depth(gams_gpu_t *h, gams_wave_plan_t *plan, uint32_t depth);
+int gams_wave_plan_select(gams_gpu_t *h, gams_wave_plan_t *plan, uint32_t age);
 /* Pipelined plans record an event behind every run, and gams_wave_peaks / gams_wave_dense wait
  * for that run only (so a host can keep several plans in flight on one handle: upload of batch
  * k+1 and its kernel overlap the readback and formatting of batch k).  Off by default: the

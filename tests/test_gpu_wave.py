@@ -243,3 +243,47 @@ def test_upload_all_ragged_batch_matches_per_ctg_content(eng):
     check(1, seqs[1])
     check(4, seqs[4])
     ss.close()
+
+
+@pytest.mark.parametrize("depth", [2, 3, 4])
+def test_depth_ways_hold_independent_identical_results(eng, s288c, depth):
+    """gams_wave_plan_set_depth: runs rotate over `depth` streams / output sets; every held run
+    equals the one-at-a-time result, also after an upload that the auxiliary streams must wait for."""
+    seqs = [bytes(s288c["I"]), bytes(s288c["Mito"])]
+    ss = engine.SeqSet(eng, seqs)
+    ref_plan = engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS | _lib.WAVE_DENSE)
+    ref_plan.run()
+    ref = ref_plan.peaks()
+    ref_dense = [ref_plan.dense(i) for i in range(2)]
+    plan = engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS | _lib.WAVE_DENSE)
+    plan.set_depth(depth)
+    for _ in range(2 * depth + 1):
+        plan.run()
+    for age in range(depth):
+        plan.select(age)
+        assert np.array_equal(plan.peaks(), ref), age
+        for i in range(2):
+            cnt, sig = plan.dense(i)
+            assert np.array_equal(cnt, ref_dense[i][0]) and np.array_equal(sig, ref_dense[i][1])
+    with pytest.raises(_lib.GamsError):
+        plan.select(depth)
+    # new bases for ctg 1: every way has to pick them up
+    mito2 = seqs[1][::-1]
+    ss.upload(1, mito2)
+    exp_cnt, _, exp_sig = ora.wave_windows(mito2, 100, 10, 100, 3.0, 1.0)
+    for _ in range(depth):
+        plan.run()
+    for age in range(depth):
+        plan.select(age)
+        cnt, sig = plan.dense(1)
+        assert np.array_equal(cnt, exp_cnt) and np.array_equal(sig, exp_sig), age
+        pk = plan.peaks()
+        mine = pk[pk["ctg"] == 1]
+        idx = np.flatnonzero(exp_sig)
+        assert np.array_equal(mine["window"], idx) and np.array_equal(mine["signal"], exp_sig[idx])
+    plan.set_depth(1)
+    plan.run()
+    assert np.array_equal(plan.dense(1)[0], exp_cnt)
+    plan.close()
+    ref_plan.close()
+    ss.close()

@@ -173,6 +173,11 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *cyc, co
         else if (MODE == 6) s = exact_dpp(K, (blockIdx.x * 13) % 3000, (uint32_t)lag, 100.0f);
         else if (MODE == 7) s = exact_sgpr<100>(K, (blockIdx.x * 13) % 3000, 100.0f);
         else if (MODE == 8) s = exact_sgpr8<100>(K, (blockIdx.x * 13) % 3000, 100.0f);
+        else if (MODE == 9) {   // cold: only one workgroup in 64 runs the evaluation, once
+            if (blockIdx.x % 64 == 5) s = exact_sgpr8<100>(K, (blockIdx.x * 13) % 3000, 100.0f);
+        } else if (MODE == 10) {
+            if (blockIdx.x % 64 == 5) s = exact_dpp(K, (blockIdx.x * 13) % 3000, (uint32_t)lag, 100.0f);
+        }
         asm volatile("" : "+v"(s));
         t1 = __builtin_readcyclecounter();
         if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
@@ -214,6 +219,22 @@ int main() {
         run<6>("exact path today (row DPP chain), lag 100", 200, d, c, kin, threads);
         run<7>("exact path via v_readlane -> SGPR + v_add, lag 100", 200, d, c, kin, threads);
         run<8>("exact path via 8 SGPRs ahead + v_add, lag 100", 200, d, c, kin, threads);
+    }
+    // cold instruction cache: first and only launch of these instantiations, 4 of 256 workgroups evaluate
+    {
+        std::vector<unsigned long long> h(256);
+        hipLaunchKernelGGL(k<9>, dim3(256), dim3(256), 0, 0, d, c, kin, 100);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h.data(), c, 256 * 8, hipMemcpyDeviceToHost);
+        printf("cold, SGPR chain: %llu %llu %llu %llu cycles (others, skipping: %llu)\n", h[5], h[69], h[133], h[197], h[6]);
+        hipLaunchKernelGGL(k<10>, dim3(256), dim3(256), 0, 0, d, c, kin, 100);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h.data(), c, 256 * 8, hipMemcpyDeviceToHost);
+        printf("cold, DPP chain:  %llu %llu %llu %llu cycles (others, skipping: %llu)\n", h[5], h[69], h[133], h[197], h[6]);
+        hipLaunchKernelGGL(k<9>, dim3(256), dim3(256), 0, 0, d, c, kin, 100);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h.data(), c, 256 * 8, hipMemcpyDeviceToHost);
+        printf("second launch, SGPR chain: %llu %llu %llu %llu cycles\n", h[5], h[69], h[133], h[197]);
     }
     // both exact variants against the sequential f32 evaluation on the host
     for (int mode = 6; mode <= 8; ++mode) {
