@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -34,6 +35,7 @@ struct gams_gpu {
     uint64_t hbm = 0;
     char arch[64] = {0};
     std::string err;
+    std::mutex err_mu;
     // Freed HBM / pinned-host blocks kept for the next batch: hipMalloc of a few hundred MB and
     // hipHostMalloc of the peak buffer cost milliseconds each (13 ms + 5 ms per 384-Mb batch).
     struct Block {
@@ -49,7 +51,10 @@ hipError_t gams_pool_alloc(gams_gpu_t *h, bool pinned, size_t bytes, void **out,
 void gams_pool_free(gams_gpu_t *h, bool pinned, void *p, size_t cap);
 
 inline int gams_fail(gams_gpu_t *h, int code, const std::string &msg) {
-    if (h) h->err = msg;
+    if (h) {
+        std::lock_guard<std::mutex> lk(h->err_mu);   // gams_wave_run_n queues from two host threads
+        h->err = msg;
+    }
     return code;
 }
 

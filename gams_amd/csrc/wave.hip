@@ -31,7 +31,11 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <type_traits>
 
 namespace {
@@ -1000,6 +1004,7 @@ __global__ __launch_bounds__(64) void wave_gather_kernel(const gams_peak_t *slot
 // =============================================================================
 // host side
 // =============================================================================
+struct Launcher;
 struct gams_wave_plan {
     gams_seqset_t *set = nullptr;
     gams_wave_params_t prm{};
@@ -1056,10 +1061,12 @@ struct gams_wave_plan {
     uint8_t *arena_fixed = nullptr, *arena_geom = nullptr;
     size_t arena_fixed_bytes = 0, arena_geom_bytes = 0;
     bool ran = false;
+    struct Launcher *launcher = nullptr;   // second host thread of gams_wave_run_n (made on first use)
     bool pipelined = false;       // gams_wave_plan_set_pipelined: an event per run; readers wait on it
     bool attr_set = false;        // dynamic-LDS attribute applied for the current geometry
     float g0 = 0, g1 = 0, g2 = 0, g3 = 0;
 };
+static void wave_launcher_stop(gams_wave_plan_t *p);
 
 namespace {
 
@@ -1386,6 +1393,7 @@ int gams_wave_plan_create(gams_gpu_t *h, gams_seqset_t *s, const gams_wave_param
 
 void gams_wave_plan_destroy(gams_gpu_t *h, gams_wave_plan_t *p) {
     if (!p) return;
+    wave_launcher_stop(p);
     if (h) {
         (void)hipSetDevice(h->device);
         for (uint32_t k = 0; k < p->depth; ++k)
@@ -1429,10 +1437,9 @@ int gams_wave_plan_set_tile(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tile_wi
     return wave_upload_geometry(h, p);
 }
 
-int gams_wave_run(gams_gpu_t *h, gams_wave_plan_t *p) {
-    if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_run: null argument");
-    GAMS_HIP(h, hipSetDevice(h->device));
-    const uint32_t k = (uint32_t)(p->run_idx % p->depth);
+// One pass on way k: touches only that way's state and its stream (run_n drives different ways
+// from different host threads); everything else it reads is fixed once the plan exists.
+static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
     gams_wave_plan::Way &w = p->way[k];
     hipStream_t st = wave_stream(h, k);
     // inputs: the way's stream queues behind the uploads and the plan's const table (no host wait)
@@ -1451,11 +1458,7 @@ int gams_wave_run(gams_gpu_t *h, gams_wave_plan_t *p) {
     if (slot == 0 && w.runs > 0)
         GAMS_HIP(h, hipMemsetAsync(w.d_counters, 0, kCounterRing * kSlotWords * sizeof(unsigned long long), st));
     ++w.runs;
-    ++p->run_idx;
     w.last_ring = slot;
-    p->last_way = k;
-    p->sel_age = 0;
-    p->ran = true;
     if (p->pipelined && !w.done) GAMS_HIP(h, hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
     if (p->tiles.empty()) {
         if (p->pipelined) GAMS_HIP(h, hipEventRecord(w.done, st));
@@ -1540,11 +1543,124 @@ int gams_wave_plan_set_pipelined(gams_gpu_t *h, gams_wave_plan_t *p, int enable)
     return GAMS_OK;
 }
 
-int gams_wave_run_n(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t n) {
-    for (uint32_t i = 0; i < n; ++i) {
-        int rc = gams_wave_run(h, p);
+int gams_wave_run(gams_gpu_t *h, gams_wave_plan_t *p) {
+    if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_run: null argument");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    const uint32_t k = (uint32_t)(p->run_idx % p->depth);
+    int rc = wave_pass_on_way(h, p, k);
+    if (rc != GAMS_OK) return rc;
+    ++p->run_idx;
+    p->last_way = k;
+    p->sel_age = 0;
+    p->ran = true;
+    return GAMS_OK;
+}
+
+// The second queueing thread of gams_wave_run_n.  It lives as long as the plan (binding a new host
+// thread to the device costs ~100 us, more than a short batch), sleeps between batches and, once
+// armed, spins until the caller has queued the first round.
+struct Launcher {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool armed = false, quit = false, finished = true;
+    std::atomic<int> go{0};            // 0: wait, 1: run the job, 2: skip it
+    gams_gpu_t *h = nullptr;
+    gams_wave_plan_t *p = nullptr;
+    uint64_t first = 0;
+    uint32_t rest = 0;
+    int rc = GAMS_OK;
+};
+
+static int wave_queue_parity(gams_gpu_t *h, gams_wave_plan_t *p, uint64_t first, uint32_t rest, uint32_t parity) {
+    for (uint32_t j = 0; j < rest; ++j) {
+        const uint32_t k = (uint32_t)((first + j) % p->depth);
+        if ((k & 1u) != parity) continue;
+        const int rc = wave_pass_on_way(h, p, k);
         if (rc != GAMS_OK) return rc;
     }
+    return GAMS_OK;
+}
+
+static void wave_launcher_main(Launcher *L, int device) {
+    const bool bound = hipSetDevice(device) == hipSuccess;
+    std::unique_lock<std::mutex> lk(L->mu);
+    for (;;) {
+        L->cv.wait(lk, [&] { return L->armed || L->quit; });
+        if (L->quit) return;
+        L->armed = false;
+        lk.unlock();
+        int g;
+        while ((g = L->go.load(std::memory_order_acquire)) == 0) __builtin_ia32_pause();
+        int rc = GAMS_OK;
+        if (g == 1) rc = bound ? wave_queue_parity(L->h, L->p, L->first, L->rest, 1u) : GAMS_EHIP;
+        lk.lock();
+        L->rc = rc;
+        L->finished = true;
+        L->cv.notify_all();
+    }
+}
+
+static void wave_launcher_stop(gams_wave_plan_t *p) {
+    Launcher *L = p->launcher;
+    if (!L) return;
+    {
+        std::lock_guard<std::mutex> lk(L->mu);
+        L->quit = true;
+    }
+    L->cv.notify_all();
+    L->th.join();
+    delete L;
+    p->launcher = nullptr;
+}
+
+int gams_wave_run_n(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t n) {
+    if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_run_n: null argument");
+    // One host thread queues a pass every ~3.3 us (hipLaunchKernelGGL); with three or four passes
+    // in flight that is slower than the device drains them (2.85 us per 12-Mb pass), so a batch is
+    // queued by two threads, each owning the ways of one parity.  The first round goes through
+    // gams_wave_run on the caller: it applies the kernel attribute and the first-use stream waits.
+    const bool threaded = p->depth >= 3 && n >= 4 * p->depth;
+    if (!threaded) {
+        for (uint32_t i = 0; i < n; ++i) {
+            int rc = gams_wave_run(h, p);
+            if (rc != GAMS_OK) return rc;
+        }
+        return GAMS_OK;
+    }
+    if (!p->launcher) {
+        p->launcher = new Launcher();
+        p->launcher->th = std::thread(wave_launcher_main, p->launcher, h->device);
+    }
+    Launcher *L = p->launcher;
+    const uint32_t lead = p->depth;
+    const uint32_t rest = n - lead;
+    const uint64_t first = p->run_idx + lead;     // index of the first pass the two threads share
+    {
+        std::lock_guard<std::mutex> lk(L->mu);
+        L->h = h;
+        L->p = p;
+        L->first = first;
+        L->rest = rest;
+        L->go.store(0, std::memory_order_relaxed);
+        L->finished = false;
+        L->armed = true;
+    }
+    L->cv.notify_all();                            // wakes up while the first round is queued
+    int rc = GAMS_OK;
+    for (uint32_t i = 0; i < lead && rc == GAMS_OK; ++i) rc = gams_wave_run(h, p);
+    L->go.store(rc == GAMS_OK ? 1 : 2, std::memory_order_release);
+    if (rc == GAMS_OK) rc = wave_queue_parity(h, p, first, rest, 0u);
+    {
+        std::unique_lock<std::mutex> lk(L->mu);
+        L->cv.wait(lk, [&] { return L->finished; });
+        if (rc == GAMS_OK) rc = L->rc;
+    }
+    if (rc != GAMS_OK) return rc;
+    p->run_idx = first + rest;
+    p->last_way = (uint32_t)((p->run_idx - 1) % p->depth);
+    p->sel_age = 0;
+    p->ran = true;
     return GAMS_OK;
 }
 
