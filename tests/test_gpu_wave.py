@@ -287,3 +287,27 @@ def test_depth_ways_hold_independent_identical_results(eng, s288c, depth):
     plan.close()
     ref_plan.close()
     ss.close()
+
+
+@pytest.mark.parametrize("depth,n", [(1, 40), (2, 40), (3, 100), (4, 257)])
+def test_run_n_equals_repeated_run(eng, s288c, depth, n):
+    """gams_wave_run_n (two queueing host threads from depth 3 on) leaves the same held passes as n calls of
+    gams_wave_run; counters of every pass are intact."""
+    seqs = [bytes(s288c["I"]), synth(200000, 11).tobytes()]
+    ss = engine.SeqSet(eng, seqs)
+    plan = engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS)
+    plan.run()
+    ref = plan.peaks()
+    ref_exact = plan.exact_count()
+    plan.set_depth(depth)
+    for rep in range(3):                       # several batches: the launcher thread is reused
+        plan.run_n(n)
+        for age in range(depth):
+            plan.select(age)
+            assert np.array_equal(plan.peaks(), ref), (rep, age)
+            assert plan.exact_count() == ref_exact
+    plan.run()                                  # mixing single runs with batches keeps the rotation
+    plan.run_n(5)
+    assert np.array_equal(plan.peaks(), ref)
+    plan.close()
+    ss.close()
