@@ -58,6 +58,10 @@ def load():
     L.gams_host_encode_gz.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.gams_host_loader_records.restype = C.c_void_p
     L.gams_host_loader_records.argtypes = [C.c_void_p, C.c_uint32, sp, sp, ip, ip, C.c_char_p, C.c_char_p]
+    L.gams_host_tsv_ctgs.restype = C.c_void_p
+    L.gams_host_tsv_ctgs.argtypes = [C.c_uint32, sp, sp, ip, ip]
+    L.gams_host_loader_tsv.restype = C.c_void_p
+    L.gams_host_loader_tsv.argtypes = [C.c_void_p, C.c_uint32, sp, sp, ip, ip, C.c_char_p, C.c_char_p]
     L.gams_host_peak.restype = C.c_void_p
     L.gams_host_peak.argtypes = [C.c_void_p, C.c_uint32, sp, sp, ip, ip, C.POINTER(C.c_void_p), C.c_char_p]
     L.gams_host_gen.restype = C.c_void_p
@@ -194,6 +198,19 @@ def loader_records(eng, ctgs, lines, tag=None):
     out = _take(load().gams_host_loader_records(eng.h, n, ids, chrs, st.ctypes.data, en.ctypes.data,
                                                 "\n".join(lines).encode(), tag.encode() if tag is not None else None))
     return [tuple(r.split("\t", 1)) for r in out.splitlines()]
+
+
+def tsv_ctgs(ctgs):
+    """`gams tsv -s "ctg:*"` for these ctgs (tsv.rs:31-71)."""
+    n, ids, chrs, st, en = _ctg_arrays(ctgs)
+    return _take(load().gams_host_tsv_ctgs(n, ids, chrs, st.ctypes.data, en.ctypes.data))
+
+
+def loader_tsv(eng, ctgs, lines, tag=None):
+    """`gams tsv -s "rg:*"` / `"feature:*"` of what the loaders would have stored."""
+    n, ids, chrs, st, en = _ctg_arrays(ctgs)
+    return _take(load().gams_host_loader_tsv(eng.h, n, ids, chrs, st.ctypes.data, en.ctypes.data,
+                                             "\n".join(lines).encode(), tag.encode() if tag is not None else None))
 
 
 def peak(eng, ctgs, lines):

@@ -771,6 +771,39 @@ std::string json_escape(const std::string &v) {
 }
 }  // namespace
 
+std::string tsv_ctgs(const std::vector<Ctg> &ctgs) {
+    std::string out = "id\trange\tchr_id\tchr_start\tchr_end\tchr_strand\tlength\n";   // data.rs:5-14
+    for (const Ctg &c : ctgs)
+        out += c.id + "\t" + c.range + "\t" + c.chr_id + "\t" + std::to_string(c.chr_start) + "\t" +
+               std::to_string(c.chr_end) + "\t" + c.chr_strand + "\t" + std::to_string(c.length) + "\n";
+    return out;
+}
+
+std::string tsv_records(const std::vector<Record> &records, bool features) {
+    std::string out = features ? "id\trange\tlength\ttag\n" : "id\trange\n";           // data.rs:16-28
+    for (const Record &r : records) {
+        // values of the flat JSON object this library wrote itself, in field order
+        std::string row;
+        size_t pos = 0;
+        while ((pos = r.json.find("\":", pos)) != std::string::npos) {
+            pos += 2;
+            std::string v;
+            if (r.json[pos] == '"') {
+                for (++pos; pos < r.json.size() && r.json[pos] != '"'; ++pos) {
+                    if (r.json[pos] == '\\' && pos + 1 < r.json.size()) ++pos;
+                    v += r.json[pos];
+                }
+            } else {
+                while (pos < r.json.size() && r.json[pos] != ',' && r.json[pos] != '}') v += r.json[pos++];
+            }
+            if (!row.empty()) row += '\t';
+            row += v;
+        }
+        out += row + "\n";
+    }
+    return out;
+}
+
 std::vector<Record> rg_records(Locator &loc, const std::vector<std::string> &lines) {
     std::vector<Record> out;
     for (auto &kv : read_range(loc, lines)) {                           // BTreeMap order = ctg id order

@@ -146,6 +146,11 @@ std::vector<Peak> peak_records(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq
 struct Record {
     std::string key, json;
 };
+// src/cmd_gams/tsv.rs:31-71: `gams tsv -s "ctg:*"` = a header of the struct's field names
+// (data.rs:5-14, serde order) and one tab-separated row per record; ctgs in the order given.
+std::string tsv_ctgs(const std::vector<Ctg> &ctgs);
+// the same for "feature:*" / "rg:*" records: the JSON objects' values in field order
+std::string tsv_records(const std::vector<Record> &records, bool features);
 std::vector<Record> rg_records(Locator &loc, const std::vector<std::string> &lines);
 std::vector<Record> feature_records(Locator &loc, const std::vector<std::string> &lines, const std::string &tag);
 

@@ -208,6 +208,18 @@ char *gams_host_loader_records(gams_gpu_t *h, uint32_t n, const char *const *ids
     });
 }
 
+// tsv.rs for "rg:*" (tag == NULL) / "feature:*" records of the loaders above
+char *gams_host_loader_tsv(gams_gpu_t *h, uint32_t n, const char *const *ids, const char *const *chrs,
+                           const int32_t *starts, const int32_t *ends, const char *lines, const char *tag) {
+    return guarded([&] {
+        gams::Locator loc(h, make_ctgs(n, ids, chrs, starts, ends));
+        std::vector<std::string> first_cols;
+        for (const std::string &ln : split_lines(lines)) first_cols.push_back(ln.substr(0, ln.find('\t')));
+        return gams::tsv_records(tag ? gams::feature_records(loc, first_cols, tag) : gams::rg_records(loc, first_cols),
+                                 tag != nullptr);
+    });
+}
+
 // gzip framing of seq: values (redis.rs:149-161); *out_len receives the length
 char *gams_host_decode_gz(const uint8_t *bytes, uint64_t n, uint64_t *out_len) {
     return guarded([&] {
@@ -288,6 +300,12 @@ char *gams_host_gen(gams_gpu_t *h, const char *chr_id, const uint8_t *seq, uint6
                    std::to_string(c.chr_end) + "\t" + c.chr_strand + "\t" + std::to_string(c.length) + "\n";
         return out;
     });
+}
+
+// tsv.rs:31-71 for "ctg:*" (no device work)
+char *gams_host_tsv_ctgs(uint32_t n, const char *const *ids, const char *const *chrs, const int32_t *starts,
+                         const int32_t *ends) {
+    return guarded([&] { return gams::tsv_ctgs(make_ctgs(n, ids, chrs, starts, ends)); });
 }
 
 // formatting helpers exposed for CPU-only tests

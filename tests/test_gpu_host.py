@@ -357,3 +357,19 @@ def test_command_rg_and_feature_records(eng, s288c):
         assert rec == {"id": k, "range": rng, "length": e - s + 1, "tag": "spo11"}
         assert list(rec) == ["id", "range", "length", "tag"]           # serde field order (data.rs:16-22)
     assert json.loads(rg[5][1]) == {"id": rg[5][0], "range": host.read_range(eng, ctgs, lines)[5][1]}
+
+
+def test_command_tsv_of_loader_records(eng, s288c):
+    """tsv.rs:31-71 over what `gams feature` / `gams rg` stored: header = struct fields (data.rs:16-28)."""
+    ctgs = all_ctgs(s288c)
+    lines = helpers.read_lines("spo11_hot.rg")
+    ft = host.loader_tsv(eng, ctgs, lines, tag="spo11").splitlines()
+    rg = host.loader_tsv(eng, ctgs, lines).splitlines()
+    assert ft[0] == "id\trange\tlength\ttag" and rg[0] == "id\trange"
+    assert len(ft) == 70 and len(rg) == 70
+    recs = host.loader_records(eng, ctgs, lines, tag="spo11")
+    import json
+
+    for row, (k, js) in zip(ft[1:], recs):
+        rec = json.loads(js)
+        assert row.split("\t") == [rec["id"], rec["range"], str(rec["length"]), rec["tag"]]

@@ -52,3 +52,20 @@ def test_gzip_framing_of_seq_values():
     assert host.decode_gz(blob) == gzip.decompress(blob)         # the reference's own fixture
     with pytest.raises(host.HostError):
         host.decode_gz(b"not a gzip member")
+
+
+def test_command_tsv_ctgs_reproduces_the_fixture():
+    """tests/cli.rs:214-233 (`gams tsv -s "ctg:*"`: 4 lines, 7 fields, header names) and the rows of
+    tests/S288c/ctg.tsv, which the reference made the same way (README.md recipe)."""
+    import helpers
+
+    lines = helpers.read_lines("ctg.tsv")
+    ctgs = []
+    for row in lines[1:]:
+        f = row.split("\t")
+        ctgs.append(dict(id=f[0], chr_id=f[2], chr_start=int(f[3]), chr_end=int(f[4]), seq=b""))
+    out = host.tsv_ctgs(ctgs).splitlines()
+    assert len(out) == 4 and len(out[0].split("\t")) == 7
+    assert "chr_strand\tlength" in out[0] and any("ctg:I:2" in r for r in out)
+    assert out[0] == lines[0]
+    assert out[1:] == lines[1:]
