@@ -26,7 +26,7 @@ __device__ __forceinline__ uint32_t eq_nocase(uint32_t x) {
 }
 
 __device__ __forceinline__ uint32_t valid_flags(uint32_t x) {
-    // G/C/g/c: (b & 0xDB) == 0x43 (see wave.hip); A/a: 0x41; T/t: 0x54
+    // G/C/g/c: (b & 0xDB) == 0x43 (see wave_kernels.hpp); A/a: 0x41; T/t: 0x54
     const uint32_t t = ((x & 0x5B5B5B5Bu) ^ 0x43434343u) + 0x7F7F7F7Fu;
     const uint32_t gc = ~(t | x | 0x7F7F7F7Fu);
     return gc | eq_nocase<0x41>(x) | eq_nocase<0x54>(x);

@@ -1,0 +1,967 @@
+// wave_kernels.hpp -- device side of the wave path (included by wave.hip only): the argument
+// block, the two tile kernels, the serial / compaction / packing kernels.  See wave.hip for the
+// scheme and the host side.
+#pragma once
+
+#include "common.hpp"
+
+#include <type_traits>
+
+namespace {
+
+struct WaveCtgDev {
+    uint64_t seq_off;   // byte offset of the ctg in the seqset buffer (256-B aligned)
+    uint64_t win_base;  // index of the ctg's window 0 in the dense outputs
+    uint32_t len;       // bases
+    uint32_t n_win;     // windows
+};
+
+struct WaveTile {
+    uint32_t ctg;
+    uint32_t w0;        // first window of the tile
+    uint32_t n_win;     // windows of the ctg
+    uint32_t pad;
+    uint64_t seq_off;   // copy of the ctg's geometry: one load per workgroup instead of two dependent ones
+    uint64_t win_base;
+};
+
+// Peak records: every tile owns a fixed slot of `tile_cap` records (tile t writes
+// peaks[t*tile_cap ...] and its count to tile_cnt[t]): no atomic, no ordering between
+// workgroups; gams_wave_peaks() packs the slots on the device.  (A single appended-to
+// counter serialises at ~88 atomics/us; 128 sharded counters still put a returning atomic
+// on every workgroup's critical path.)  The diagnostics counters stay sharded: one word
+// serialises at ~88 atomics/us, which a 1000-tile launch would feel.
+constexpr uint32_t kShards = 128;
+constexpr uint32_t kShardWords = 16;
+
+struct WaveArgs {
+    const uint8_t *seq;
+    const WaveCtgDev *ctgs;
+    const WaveTile *tiles;
+    uint32_t size, step, lag, tw;
+    uint32_t max_chunks;  // LDS carve: PM holds max_chunks+1 words
+    uint32_t max_win;     // LDS carve: K holds max_win, Q1/Q2 hold max_win+1
+    uint32_t flags;
+    uint32_t no_signal;   // lag == 1: std is NaN (0/0), the reference never signals
+    float thr, thr_abs, fsize, flag_f, cvar;
+    float g0, g1, g2, g3;  // guard band  G = g0 + g1*S1 + g2*R + g3*D
+    // outputs
+    gams_peak_t *peaks;
+    uint32_t tile_cap;             // records per tile slot of `peaks`
+    unsigned long long *counters;  // kShards x 16 words (one 128-B line per shard): [1] exact-path evaluations
+    uint32_t *tile_cnt;
+    uint32_t *dense_cnt;
+    int8_t *dense_sig;
+    const int8_t *const_sig;  // [size+1]: signal when the lag counts and the window's count all equal k
+    unsigned long long *stamps;  // diagnostics: [tile][8] s_memtime at phase boundaries (NULL: off)
+};
+
+// Phase stamp of a diagnostic run (gams_wave_plan_set_stamps): thread 0 of the
+// workgroup stores the shader clock.  Off (stamps == NULL) it is one scalar branch.
+__device__ __forceinline__ void wave_stamp(const WaveArgs &a, int slot) {
+    if (a.stamps != nullptr && threadIdx.x == 0) {
+        // 16 words (one 128-B line) per workgroup: [0..6] shader clock at the phase
+        // boundaries, [8] / [9] the constant 100 MHz clock at workgroup start / end
+        a.stamps[(size_t)blockIdx.x * 16 + slot] = __builtin_readcyclecounter();
+        if (slot == 0) {
+            a.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memrealtime();
+            // where it ran: HW_ID (wave/simd/cu/sh/se) and XCC_ID
+            a.stamps[(size_t)blockIdx.x * 16 + 11] =
+                ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) |
+                (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        }
+        if (slot == 6) a.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+// ---- G/C/g/c classification of 16 packed bytes -> 16-bit mask ------------------
+// 'C' 0x43, 'G' 0x47, 'c' 0x63, 'g' 0x67 are exactly the bytes with
+// (b & 0xDB) == 0x43 (0xDB drops the case bit 0x20 and the C/G bit 0x04), i.e.
+// bit 7 clear and (b & 0x5B) == 0x43.  Per dword: t = ((x & 0x5B..) ^ 0x43..) + 0x7F..
+// sets bit 7 of every byte whose low part differs (no carry leaves a byte:
+// <= 0x5B + 0x7F), so ~(t | x) has bit 7 set exactly on G/C/g/c bytes.  On gfx950
+// this is v_bitop3 + v_add + v_bitop3.  The four flag bits of a dword are then
+// gathered by v_dot4_u32_u8 against bit weights (0x80 * weight, undone by >> 7).
+__device__ __forceinline__ uint32_t gc_flags(uint32_t x) {
+    const uint32_t t = ((x & 0x5B5B5B5Bu) ^ 0x43434343u) + 0x7F7F7F7Fu;
+    return ~(t | x | 0x7F7F7F7Fu);  // 0x80 in every G/C/g/c byte, 0 elsewhere
+}
+
+__device__ __forceinline__ uint32_t gc_mask16(const uint4 v) {
+    // lo = 128 * (bits 0..7 of the mask), hi = 128 * (bits 8..15)
+    uint32_t lo = __builtin_amdgcn_udot4(gc_flags(v.x), 0x08040201u, 0u, false);
+    lo = __builtin_amdgcn_udot4(gc_flags(v.y), 0x80402010u, lo, false);
+    uint32_t hi = __builtin_amdgcn_udot4(gc_flags(v.z), 0x08040201u, 0u, false);
+    hi = __builtin_amdgcn_udot4(gc_flags(v.w), 0x80402010u, hi, false);
+    return (lo >> 7) | (hi << 1);
+}
+
+// #GC in tile bytes [0, x): chunk prefix + popcount of the chunk's low bits
+__device__ __forceinline__ uint32_t gc_prefix_at(const uint32_t *PM, uint32_t x) {
+    uint32_t e = PM[x >> 4];
+    uint32_t low = e & ((1u << (x & 15u)) - 1u);  // mask lives in the low 16 bits
+    return (e >> 16) + __popc(low);
+}
+
+// The reference's evaluation, bit for bit (stat.rs:1-14 and :36-38): K holds the
+// gc counts of the tile's windows, tj = first averaged window, ti = this window.
+template <typename KT>
+__device__ __noinline__ int exact_signal(const KT *K, uint32_t tj, uint32_t ti, uint32_t n,
+                                         float fsize, float thr) {
+    const float len = (float)n;
+    float sum = 0.0f;
+    for (uint32_t q = 0; q < n; ++q) sum = sum + (float)K[tj + q] / fsize;   // mean: stat.rs:3
+    const float mean = sum / len;                                             // stat.rs:5
+    float sq = 0.0f;
+    for (uint32_t q = 0; q < n; ++q) {                                        // stat.rs:12
+        const float x = (float)K[tj + q] / fsize;
+        const float d = x - mean;
+        sq = sq + d * d;
+    }
+    const float sd = sqrtf(sq / (len - 1.0f));                                // stat.rs:13
+    const float x = (float)K[ti] / fsize;
+    if (fabsf(x - mean) > thr * sd) return x > mean ? 1 : -1;                 // stat.rs:36-38
+    return 0;
+}
+
+template <typename KT, bool WIDE>
+__global__ __launch_bounds__(256) void wave_tile_kernel(const WaveArgs a) {
+    using Q2T = typename std::conditional<WIDE, uint64_t, uint32_t>::type;
+    extern __shared__ __align__(16) unsigned char smem[];
+    // LDS carve: Q2 | Q1 | PM | scratch | PC | K
+    const uint32_t mwp = (a.max_win + 3u) & ~1u;  // even element count keeps every array 8-B aligned
+    Q2T *Q2 = reinterpret_cast<Q2T *>(smem);
+    uint32_t *Q1 = reinterpret_cast<uint32_t *>(Q2 + mwp);
+    uint32_t *PM = Q1 + mwp;
+    uint64_t *scr = reinterpret_cast<uint64_t *>(PM + ((a.max_chunks + 4) & ~1u));
+    uint32_t *PC = reinterpret_cast<uint32_t *>(scr + 8);  // 128 per-(iteration,wave) peak counts + base
+    KT *K = reinterpret_cast<KT *>(PC + 132);
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const WaveTile tl = a.tiles[blockIdx.x];
+    const struct { uint64_t seq_off, win_base; uint32_t n_win; } cg = {tl.seq_off, tl.win_base, tl.n_win};
+    const uint32_t lag = a.lag, step = a.step, size = a.size;
+    const uint32_t w0 = tl.w0;
+    const uint32_t w1 = min(w0 + a.tw, cg.n_win);
+    const uint32_t wh = w0 > lag ? w0 - lag - 1u : 0u;   // first window whose gc is needed
+    const uint32_t nw = w1 - wh;
+    const uint32_t b0 = wh * step;                        // ctg-relative byte of window wh
+    const uint32_t a0 = b0 & ~15u;                        // tile byte 0 (16-B aligned)
+    const uint32_t b1 = (w1 - 1u) * step + size;          // exclusive end, <= cg.len
+    const uint32_t nchunk = (b1 - a0 + 15u) >> 4;
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.seq + cg.seq_off + a0);
+
+    // ---- phase 1: load + classify ------------------------------------------
+    for (uint32_t c = tid; c < nchunk; c += 1024u) {
+        const uint32_t c1 = c + 256u, c2 = c + 512u, c3 = c + 768u;
+        uint4 v0 = src[c];
+        uint4 v1 = make_uint4(0, 0, 0, 0), v2 = v1, v3 = v1;
+        if (c1 < nchunk) v1 = src[c1];
+        if (c2 < nchunk) v2 = src[c2];
+        if (c3 < nchunk) v3 = src[c3];
+        PM[c] = gc_mask16(v0);
+        if (c1 < nchunk) PM[c1] = gc_mask16(v1);
+        if (c2 < nchunk) PM[c2] = gc_mask16(v2);
+        if (c3 < nchunk) PM[c3] = gc_mask16(v3);
+    }
+    __syncthreads();
+
+    // ---- phase 1b: exclusive prefix of chunk popcounts ----------------------
+    {
+        const uint32_t cpt = ((nchunk + 255u) >> 8) | 1u;  // odd stride: conflict-free LDS walks
+        const uint32_t cb = min(tid * cpt, nchunk), ce = min(cb + cpt, nchunk);
+        uint32_t s = 0;
+        for (uint32_t c = cb; c < ce; ++c) s += __popc(PM[c]);
+        uint32_t tot;
+        uint32_t run = block_excl_scan_256<uint32_t>(s, reinterpret_cast<uint32_t *>(scr), tot);
+        for (uint32_t c = cb; c < ce; ++c) {
+            const uint32_t m = PM[c];
+            PM[c] = (run << 16) | m;
+            run += __popc(m);
+        }
+        if (cb < ce && ce == nchunk) PM[nchunk] = run << 16;  // sentinel for x on the tile end
+    }
+    __syncthreads();
+
+    // ---- phase 2: window counts + prefixes of k and k^2 ---------------------
+    {
+        const uint32_t wpt = ((nw + 255u) >> 8) | 1u;
+        const uint32_t tb = min(tid * wpt, nw), te = min(tb + wpt, nw);
+        uint32_t s1 = 0;
+        Q2T s2 = 0;
+        uint32_t x = (wh + tb) * step - a0;
+        for (uint32_t t = tb; t < te; ++t, x += step) {
+            const uint32_t kk = gc_prefix_at(PM, x + size) - gc_prefix_at(PM, x);
+            K[t] = (KT)kk;
+            s1 += kk;
+            s2 += (Q2T)kk * kk;
+        }
+        uint32_t tot1;
+        Q2T tot2;
+        uint32_t q1 = block_excl_scan_256<uint32_t>(s1, reinterpret_cast<uint32_t *>(scr), tot1);
+        Q2T q2 = block_excl_scan_256<Q2T>(s2, reinterpret_cast<Q2T *>(scr), tot2);
+        for (uint32_t t = tb; t < te; ++t) {
+            Q1[t] = q1;
+            Q2[t] = q2;
+            const uint32_t kk = K[t];
+            q1 += kk;
+            q2 += (Q2T)kk * kk;
+        }
+        if (tb < te && te == nw) {
+            Q1[nw] = q1;
+            Q2[nw] = q2;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: z-score decision per window -------------------------------
+    const bool want_peaks = (a.flags & GAMS_WAVE_PEAKS) != 0;
+    const bool want_dense = (a.flags & GAMS_WAVE_DENSE) != 0;
+    const uint32_t R = a.tw >> 8;  // iterations per thread, <= 32
+    uint64_t sigbits = 0;          // 2 bits per iteration: 1 = crest, 3 = trough
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t i = w0 + (r << 8) + tid;
+        int sg = 0;
+        if (i < w1) {
+            const uint32_t ti = i - wh;
+            const uint32_t kk = K[ti];
+            if (i >= lag && !a.no_signal) {
+                const uint32_t tj = (i == lag ? 0u : i - 1u - lag) - wh;
+                const uint32_t S1 = Q1[tj + lag] - Q1[tj];
+                const Q2T S2 = Q2[tj + lag] - Q2[tj];
+                const int64_t di = (int64_t)lag * kk - (int64_t)S1;   // n*k - S1, sign = side of the mean
+                float Df, Vf;
+                if (WIDE) {
+                    const uint64_t D = (uint64_t)(di < 0 ? -di : di);
+                    const uint64_t V = (uint64_t)lag * (uint64_t)S2 - (uint64_t)S1 * S1;
+                    Df = (float)D;
+                    Vf = (float)V;
+                } else {
+                    const uint32_t D = (uint32_t)(di < 0 ? -di : di);
+                    const uint32_t V = lag * (uint32_t)S2 - S1 * S1;
+                    Df = (float)D;
+                    Vf = (float)V;
+                }
+                const float Rf = a.thr_abs * __builtin_amdgcn_sqrtf(a.cvar * Vf);
+                const float diff = Df - Rf;
+                const float G = a.g0 + a.g1 * (float)S1 + a.g2 * Rf + a.g3 * Df;
+                if (fabsf(diff) > G) {
+                    sg = diff > 0.0f ? (di > 0 ? 1 : -1) : 0;
+                } else {
+                    sg = exact_signal<KT>(K, tj, ti, lag, a.fsize, a.thr);
+                    atomicAdd(&a.counters[(blockIdx.x & (kShards - 1u)) * kShardWords + 1u], 1ull);
+                }
+            }
+            if (want_dense) {
+                a.dense_cnt[cg.win_base + i] = kk;
+                a.dense_sig[cg.win_base + i] = (int8_t)sg;
+            }
+        }
+        if (want_peaks) {
+            const unsigned long long bal = __ballot(sg != 0);
+            if (lane == 0) PC[(r << 2) + wv] = (uint32_t)__popcll(bal);
+            sigbits |= (uint64_t)(sg & 3) << (2u * r);
+        }
+    }
+
+    // ---- phase 4: ordered compaction of the tile's peaks ---------------------
+    if (want_peaks) {
+        __syncthreads();
+        const uint32_t ncell = R << 2;
+        const uint32_t mine = tid < ncell ? PC[tid] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_256<uint32_t>(mine, reinterpret_cast<uint32_t *>(scr), tot);
+        if (tid < ncell) PC[tid] = ex;
+        if (tid == 0) a.tile_cnt[blockIdx.x] = tot;
+        const uint32_t base = 0;
+        gams_peak_t *const region = a.peaks + (size_t)blockIdx.x * a.tile_cap;
+        if (tot) {
+            for (uint32_t r = 0; r < R; ++r) {
+                const uint32_t code = (uint32_t)(sigbits >> (2u * r)) & 3u;
+                const unsigned long long bal = __ballot(code != 0);
+                if (code) {
+                    const uint32_t i = w0 + (r << 8) + tid;
+                    const uint32_t pos = base + PC[(r << 2) + wv] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                    if (pos < a.tile_cap) {
+                        gams_peak_t pk;
+                        pk.ctg = tl.ctg;
+                        pk.window = i;
+                        pk.gc_count = K[i - wh];
+                        pk.signal = code == 1u ? 1 : -1;
+                        region[pos] = pk;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Same evaluation, executed by a whole wavefront for ONE window: the lanes fetch and
+// convert the lag counts in parallel; only the two f32 sums stay sequential, in the
+// reference's order.  Every lane returns the same signal.  Control flow must be wave-uniform
+// at the call.
+// carry + x[B] + x[B+1] + ... + x[B+7] (lane values of x), added strictly left to right.
+// The eight lane values go to eight SGPRs first (v_readlane, independent of the sum), then one
+// plain dependent v_add_f32 per element with an SGPR operand: 8 + 8 issue slots per 8 elements.
+// The empty asm pins all eight in SGPRs before the first add, so that no add waits for its own
+// v_readlane (the compiler's single-SGPR version needs an s_nop 1 per element).
+// Cycles per lag-100 evaluation, alone on a SIMD (tools/dep_latency.hip): 2349, against 4952
+// for the row-DPP chain (s_nop 1 + v_add_f32_dpp row_shr:1 per element) this replaced and
+// 3733 for the single-SGPR form.  Inside the S288c launch an evaluation still costs ~4.9k
+// cycles (5.7k before): the code runs a few dozen times per launch, each time cold on its CU.
+// Tried and dropped: terms through LDS with broadcast ds_read_b128 + VGPR adds (8.4k cycles in
+// the kernel: the loop control eats the shorter chain), and inlining everything (scratch
+// spills under the 64-VGPR cap, 8.2 -> 11.7 us per launch).
+template <int B>
+__device__ __forceinline__ float seq_add8(float carry, float x) {
+    const int xi = __float_as_int(x);
+    int t0 = __builtin_amdgcn_readlane(xi, B + 0), t1 = __builtin_amdgcn_readlane(xi, B + 1),
+        t2 = __builtin_amdgcn_readlane(xi, B + 2), t3 = __builtin_amdgcn_readlane(xi, B + 3),
+        t4 = __builtin_amdgcn_readlane(xi, B + 4), t5 = __builtin_amdgcn_readlane(xi, B + 5),
+        t6 = __builtin_amdgcn_readlane(xi, B + 6), t7 = __builtin_amdgcn_readlane(xi, B + 7);
+    asm volatile("" : "+s"(t0), "+s"(t1), "+s"(t2), "+s"(t3), "+s"(t4), "+s"(t5), "+s"(t6), "+s"(t7));
+    carry = carry + __int_as_float(t0);
+    carry = carry + __int_as_float(t1);
+    carry = carry + __int_as_float(t2);
+    carry = carry + __int_as_float(t3);
+    carry = carry + __int_as_float(t4);
+    carry = carry + __int_as_float(t5);
+    carry = carry + __int_as_float(t6);
+    carry = carry + __int_as_float(t7);
+    asm volatile("" : "+v"(carry));
+    return carry;
+}
+
+// Sequential f32 sum of the first `m` lane values of `x` (m <= 64, wave-uniform) on top of
+// `carry`.  Lanes past m must hold +0.0f: the sums here are of non-negative terms and start at
+// +0.0f, so a padding term leaves them unchanged; whole groups of eight past m are skipped.
+// Out of line: one 0.8-KB body shared by the four calls of an evaluation.
+__device__ __noinline__ float seq_add_lanes(float carry, float x, uint32_t m) {
+    carry = seq_add8<0>(carry, x);
+    if (m > 8u) carry = seq_add8<8>(carry, x);
+    if (m > 16u) carry = seq_add8<16>(carry, x);
+    if (m > 24u) carry = seq_add8<24>(carry, x);
+    if (m > 32u) carry = seq_add8<32>(carry, x);
+    if (m > 40u) carry = seq_add8<40>(carry, x);
+    if (m > 48u) carry = seq_add8<48>(carry, x);
+    if (m > 56u) carry = seq_add8<56>(carry, x);
+    return carry;
+}
+
+// Inlined into the kernel, where K is known to be LDS (ds_read); behind a call boundary it is a
+// generic pointer and every count costs a flat load (~1k cycles per evaluation).  The
+// sequential part stays out of line (seq_add_lanes) and takes values, not pointers.
+__device__ __forceinline__ int exact_signal_wave(const uint8_t *K, uint32_t tj, uint32_t ti, uint32_t n,
+                                                 float fsize, float thr) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const float len = (float)n;
+    // lanes past the end contribute +0.0f, which leaves an f32 sum of non-negative terms unchanged
+    float sum = 0.0f;
+    for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+        const float x = c0 + lane < n ? (float)K[tj + c0 + lane] / fsize : 0.0f;
+        sum = seq_add_lanes(sum, x, min(64u, n - c0));                           // stat.rs:3
+    }
+    const float mean = sum / len;                                                // stat.rs:5
+    float sq = 0.0f;
+    for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+        const float x = (float)K[tj + min(c0 + lane, n - 1u)] / fsize;
+        const float d = x - mean;
+        const float dd = c0 + lane < n ? d * d : 0.0f;
+        sq = seq_add_lanes(sq, dd, min(64u, n - c0));                            // stat.rs:12
+    }
+    const float sd = sqrtf(sq / (len - 1.0f));                                   // stat.rs:13
+    const float x = (float)K[ti] / fsize;
+    if (fabsf(x - mean) > thr * sd) return x > mean ? 1 : -1;                    // stat.rs:36-38
+    return 0;
+}
+
+// const_sig[k]: the reference's verdict when the lag averaged windows and the
+// tested window all have gc count k (homopolymer / N runs: V == 0 and D == 0,
+// which the integer decision cannot settle).  One thread per k, exact order.
+__global__ void wave_const_table_kernel(int8_t *const_sig, uint32_t size, uint32_t lag, float thr) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > size) return;
+    const float fsize = (float)size, len = (float)lag;
+    const float x = (float)k / fsize;
+    float sum = 0.0f;
+    for (uint32_t q = 0; q < lag; ++q) sum = sum + x;
+    const float mean = sum / len;
+    float sq = 0.0f;
+    const float d = x - mean;
+    for (uint32_t q = 0; q < lag; ++q) sq = sq + d * d;
+    const float sd = sqrtf(sq / (len - 1.0f));
+    int sg = 0;
+    if (fabsf(x - mean) > thr * sd) sg = x > mean ? 1 : -1;
+    const_sig[k] = (int8_t)sg;
+}
+
+// =============================================================================
+// wave_fast_kernel<W,SIZE,STEP,LAG>: the tile algorithm for 8-bit counts (size <= 255),
+// step <= 32 and 32-bit variance math (lag*size <= 65535, lag*size^2 < 2^24), i.e. every
+// BASELINE configuration.  256 threads, W windows per thread, tile = 256*W windows.
+//
+//   phase 1  tile bytes HBM -> registers (16 B/lane, coalesced) -> G/C/g/c flags
+//            (v_bitop3, v_add, v_bitop3 per dword; v_dot4 gathers 4 flags) -> 16-bit mask
+//            per 16-B chunk -> LDS bit stream BM (1 bit per base).
+//   phase 2  window counts, rolling over the bit stream: k(w+1) = k(w) + popc(step bits
+//            entering) - popc(step bits leaving); stored as bytes K[].  Slot idx holds
+//            window vb+idx with vb = w0-lag-1; windows before the ctg start read as 0.
+//   phase 3  thread t owns windows w0 + t*W + [0,W).  It sums the lag counts in front of
+//            its first window once (v_dot4 on packed bytes: S1 = sum k, S2 = sum k^2) and
+//            then rolls: S(q+1) = S(q) - K[tW+q] + K[tW+q+lag].  All K traffic is whole
+//            dwords at an odd dword stride between lanes (W/4 in {1,3,5}): conflict-free.
+//            Branch-free integer decision; three sign bits per window are shifted into
+//            accumulators with v_alignbit.  Window i == lag (averages [0,lag): stat.rs:30-31) is redone by
+//            its owner.  Windows inside the guard band: const_sig table (homopolymer runs)
+//            or exact_signal_wave.
+//   phase 4  dense rows through LDS (coalesced stores) and/or per-thread peak counts ->
+//            one workgroup scan -> records in window order into the tile's fixed slot.
+// =============================================================================
+// __launch_bounds__(256, 8): 8 waves per SIMD = 8 workgroups per CU, i.e. at most 64 VGPRs.
+// Interleaved A/B (tools/ab.py) on 384 Mb: W = 12 runs 115 -> 105 us with the cap.
+// SIZE/STEP/LAG != 0 bake the headline parameters into the instruction stream (constant
+// bit-field offsets in phase 2); 0 = taken from the arguments at run time.
+template <int W, int SIZE, int STEP, int LAG>
+__global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
+    static_assert(W % 4 == 0 && ((W / 4) & 1) == 1, "W/4 must be odd (LDS bank stride)");
+    static_assert((SIZE == 0) == (STEP == 0) && (SIZE == 0) == (LAG == 0), "bake all three or none");
+    if (a.stamps != nullptr && threadIdx.x == 0)
+        a.stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();  // workgroup entry
+    constexpr uint32_t TW = 256u * W;
+    constexpr int WD = W / 4;
+    extern __shared__ __align__(16) unsigned char smem[];
+    // LDS carve: BM (1 bit per base, 16 per chunk) | scratch (16 words) | K | SG (dense only)
+    uint16_t *BM = reinterpret_cast<uint16_t *>(smem);
+    const uint32_t *BW = reinterpret_cast<const uint32_t *>(smem);
+    uint32_t *scr = reinterpret_cast<uint32_t *>(smem) + ((((a.max_chunks + 8u) >> 1) + 16u + 3u) & ~3u);
+    uint8_t *K = reinterpret_cast<uint8_t *>(scr + 16);
+    const uint32_t *KW = reinterpret_cast<const uint32_t *>(K);
+    uint8_t *SG = K + ((TW + (LAG ? (uint32_t)LAG : a.lag) + 1u + 31u) & ~15u);
+
+    const uint32_t tid = threadIdx.x;
+    const WaveTile tl = a.tiles[blockIdx.x];
+    const struct { uint64_t seq_off, win_base; uint32_t n_win; } cg = {tl.seq_off, tl.win_base, tl.n_win};
+    const uint32_t lag = LAG ? (uint32_t)LAG : a.lag, step = STEP ? (uint32_t)STEP : a.step,
+                   size = SIZE ? (uint32_t)SIZE : a.size;
+    const uint32_t w0 = tl.w0;
+    const uint32_t w1 = min(w0 + TW, cg.n_win);
+    const uint32_t nvalid = w1 - w0;
+    const int32_t vb = (int32_t)w0 - (int32_t)lag - 1;       // window held by K slot 0 (may be < 0)
+    const uint32_t wh = vb > 0 ? (uint32_t)vb : 0u;
+    const uint32_t b0 = wh * step;
+    const uint32_t a0 = b0 & ~15u;
+    const uint32_t b1 = (w1 - 1u) * step + size;
+    const uint32_t nchunk = (b1 - a0 + 15u) >> 4;
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.seq + cg.seq_off + a0);
+
+    wave_stamp(a, 0);
+    // ---- phase 1: load + classify ------------------------------------------
+    if constexpr (STEP != 0) {
+        // Baked parameters: the tile never has more than NCH chunks, so every thread issues
+        // all of its NLD loads back to back with no bounds logic (the bytes past the tile
+        // are the next tile's or the seqset's tail slack), classifies, and stores.
+        constexpr uint32_t NCH = ((uint32_t)TW * STEP + ((uint32_t)LAG + 1u) * STEP + SIZE + 30u) / 16u + 1u;
+        constexpr uint32_t NLD = (NCH + 255u) / 256u;
+        uint4 v[NLD];
+#pragma unroll
+        for (uint32_t k = 0; k + 1u < NLD; ++k) v[k] = src[tid + 256u * k];
+        // the last row is only partly inside the largest tile: lanes past it skip the load
+        // (issued last, so the predicated block delays no other load)
+        v[NLD - 1u] = make_uint4(0, 0, 0, 0);
+        if (tid + 256u * (NLD - 1u) < NCH) v[NLD - 1u] = src[tid + 256u * (NLD - 1u)];
+#pragma unroll
+        for (uint32_t k = 0; k < NLD; ++k) BM[tid + 256u * k] = (uint16_t)gc_mask16(v[k]);
+    } else
+    // Two batches of four 16-B loads stay in flight per thread: the next batch is issued
+    // before the current one is classified.  Loads and LDS stores are unconditional (index
+    // clamped to the last chunk / parked on the slot behind the last chunk, never read):
+    // a predicated load sits in its own basic block and makes hipcc wait vmcnt(0).
+    {
+        const uint32_t last = nchunk - 1u;
+        uint4 cur[4], nxt[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cur[k] = src[min(tid + 256u * k, last)];
+        for (uint32_t c0 = tid; c0 < nchunk; c0 += 1024u) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nxt[k] = src[min(c0 + 1024u + 256u * k, last)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) BM[min(c0 + 256u * k, nchunk)] = (uint16_t)gc_mask16(cur[k]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
+        }
+    }
+    __syncthreads();
+    wave_stamp(a, 1);
+    wave_stamp(a, 2);
+
+    // ---- phase 2: k of every slot, rolling over the bit stream ------------------
+    // Thread t owns a run of consecutive slots.  Its first window is counted directly
+    // (popcount of `size` bits); every further window adds the popcount of the `step`
+    // bits entering on the right and subtracts the `step` bits leaving on the left:
+    // two 64-bit LDS reads, two shifts, two masks, two popcounts per window, for any
+    // size and any step <= 32.  No byte prefix is ever built.
+    bool counted = false;
+    if constexpr (STEP != 0) {
+        // Baked parameters, tiles behind the ctg start (vb >= 0): a thread takes RUN
+        // consecutive slots, pulls the RUN*STEP + SIZE bits they span into registers once,
+        // realigns them to bit 0 (v_alignbit), and every field is then a v_bfe at a constant
+        // offset: ~6 VALU per window, no LDS access inside the run, counts stored 4 per dword.
+        if (vb >= 0) {
+            counted = true;
+            constexpr uint32_t NK_MAX = (uint32_t)LAG + 1u + TW;
+            constexpr uint32_t RUN = (((NK_MAX + 255u) / 256u) + 3u) & ~3u;
+            constexpr uint32_t NBITS = RUN * (uint32_t)STEP + (uint32_t)SIZE;
+            constexpr uint32_t NDW = (NBITS + 31u) / 32u + 1u;           // + 1 for the realignment
+            const uint32_t nK = lag + 1u + nvalid;
+            const uint32_t idx0 = tid * RUN;
+            if (idx0 < nK) {
+                const uint32_t x0 = ((uint32_t)vb + idx0) * (uint32_t)STEP - a0;
+                const uint32_t d0 = x0 >> 5, sh = x0 & 31u;
+                uint32_t r[NDW];
+#pragma unroll
+                for (uint32_t i = 0; i < NDW; ++i) r[i] = BW[d0 + i];
+#pragma unroll
+                for (uint32_t i = 0; i + 1u < NDW; ++i) r[i] = __builtin_amdgcn_alignbit(r[i + 1u], r[i], sh);
+                auto field = [&](uint32_t off) -> uint32_t {           // STEP bits at constant bit `off`
+                    const uint32_t d = off >> 5, s = off & 31u;
+                    if (s + (uint32_t)STEP <= 32u) return __builtin_amdgcn_ubfe(r[d], s, (uint32_t)STEP);
+                    return __builtin_amdgcn_alignbit(r[d + 1u], r[d], s) & ((1u << STEP) - 1u);
+                };
+                uint32_t k = 0;
+#pragma unroll
+                for (uint32_t d = 0; d < (uint32_t)SIZE / 32u; ++d) k += __popc(r[d]);
+                if constexpr (SIZE % 32 != 0) k += __popc(r[SIZE / 32] & ((1u << (SIZE % 32)) - 1u));
+                uint32_t packed = k;
+#pragma unroll
+                for (uint32_t j = 1; j < RUN; ++j) {
+                    k += __popc(field((uint32_t)SIZE + (j - 1u) * (uint32_t)STEP));
+                    k -= __popc(field((j - 1u) * (uint32_t)STEP));
+                    if ((j & 3u) == 0u) {
+                        if (idx0 + j - 4u < nK) reinterpret_cast<uint32_t *>(K)[(idx0 + j - 4u) >> 2] = packed;
+                        packed = k;
+                    } else {
+                        packed |= k << (8u * (j & 3u));
+                    }
+                }
+                if (idx0 + RUN - 4u < nK) reinterpret_cast<uint32_t *>(K)[(idx0 + RUN - 4u) >> 2] = packed;
+            }
+        }
+    }
+    if (!counted) {
+        const uint32_t nK = lag + 1u + nvalid;
+        const uint32_t run = (nK + 255u) >> 8;
+        uint32_t idx = tid * run;
+        const uint32_t iend = min(idx + run, nK);
+        for (; idx < iend && vb + (int32_t)idx < 0; ++idx) K[idx] = 0;   // before the ctg start
+        if (idx < iend) {
+            uint32_t x = (uint32_t)(vb + (int32_t)idx) * step - a0;      // bit = base position
+            // direct count of bits [x, x + size)
+            uint32_t k = 0;
+            {
+                const uint32_t e = x + size;
+                for (uint32_t d = x >> 5; d <= (e - 1u) >> 5; ++d) {
+                    uint32_t w = BW[d];
+                    const uint32_t lo = d << 5;
+                    if (lo < x) w &= ~0u << (x - lo);
+                    if (lo + 32u > e) w &= ~0u >> (lo + 32u - e);
+                    k += __popc(w);
+                }
+            }
+            K[idx++] = (uint8_t)k;
+            const uint32_t fmask = step >= 32u ? ~0u : (1u << step) - 1u;
+            // four windows per trip: all eight 64-bit LDS reads are issued before any store
+            // (K and the bit stream share the LDS array, so the compiler will not reorder them)
+            for (; idx + 4u <= iend; idx += 4u, x += 4u * step) {
+                uint32_t nl[4], nh[4], ol[4], oh[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t po = x + (uint32_t)j * step, pn = po + size;
+                    nl[j] = BW[pn >> 5];
+                    nh[j] = BW[(pn >> 5) + 1u];
+                    ol[j] = BW[po >> 5];
+                    oh[j] = BW[(po >> 5) + 1u];
+                }
+                uint32_t kq[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t po = x + (uint32_t)j * step, pn = po + size;
+                    const uint64_t wn = ((uint64_t)nh[j] << 32) | nl[j];
+                    const uint64_t wo = ((uint64_t)oh[j] << 32) | ol[j];
+                    k += __popc((uint32_t)(wn >> (pn & 31u)) & fmask);
+                    k -= __popc((uint32_t)(wo >> (po & 31u)) & fmask);
+                    kq[j] = k;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) K[idx + j] = (uint8_t)kq[j];
+            }
+            for (; idx < iend; ++idx, x += step) {
+                const uint32_t pn = x + size, po = x;
+                const uint64_t wn = ((uint64_t)BW[(pn >> 5) + 1u] << 32) | BW[pn >> 5];
+                const uint64_t wo = ((uint64_t)BW[(po >> 5) + 1u] << 32) | BW[po >> 5];
+                k += __popc((uint32_t)(wn >> (pn & 31u)) & fmask);
+                k -= __popc((uint32_t)(wo >> (po & 31u)) & fmask);
+                K[idx] = (uint8_t)k;
+            }
+        }
+    }
+    __syncthreads();
+    wave_stamp(a, 3);
+
+    // ---- phase 3: rolling sums + decision, W consecutive windows per thread ---
+    const bool want_peaks = (a.flags & GAMS_WAVE_PEAKS) != 0;
+    const bool want_dense = (a.flags & GAMS_WAVE_DENSE) != 0;
+    const uint32_t base = tid * (uint32_t)W;        // K slot of the outgoing count of window q = 0
+    uint32_t crest = 0, trough = 0;                  // one bit per owned window
+    uint32_t pend = 0;                               // windows whose decision sits inside the guard band
+    uint32_t in[WD + 1];                             // bytes K[base+lag .. base+lag+W]: incoming + own counts
+    {
+        // Every thread runs this block (wave-uniform control flow, no branches in the
+        // window loop): threads past the tile's last window read LDS inside the
+        // allocation and their decisions are masked off.
+        const uint32_t bw = base >> 2;               // dword index (W % 4 == 0)
+        uint32_t og[WD];                             // outgoing counts K[base + q]
+#pragma unroll
+        for (int d = 0; d < WD; ++d) og[d] = KW[bw + d];
+        // S1, S2 over K[base, base+lag)
+        uint32_t S1 = 0, S2 = 0;
+        const uint32_t nfull = lag >> 2;
+#pragma unroll 5
+        for (uint32_t d = 0; d < nfull; ++d) {
+            const uint32_t x = KW[bw + d];
+            S1 = __builtin_amdgcn_udot4(x, 0x01010101u, S1, false);
+            S2 = __builtin_amdgcn_udot4(x, x, S2, false);
+        }
+        const uint32_t sh = lag & 3u;                // wave-uniform
+        if (sh) {
+            const uint32_t x = KW[bw + nfull] & ((1u << (8u * sh)) - 1u);
+            S1 = __builtin_amdgcn_udot4(x, 0x01010101u, S1, false);
+            S2 = __builtin_amdgcn_udot4(x, x, S2, false);
+        }
+        {
+            const uint32_t ib = bw + nfull;
+            uint32_t lo = KW[ib];
+#pragma unroll
+            for (int d = 0; d <= WD; ++d) {
+                const uint32_t hi = KW[ib + d + 1];
+                in[d] = __builtin_amdgcn_alignbyte(hi, lo, sh);
+                lo = hi;
+            }
+        }
+        const float thr_abs = a.thr_abs, cvar = a.cvar;
+        const float g0 = a.g0, g1 = a.g1, g23 = a.g2 + a.g3;
+        // windows this thread may decide: inside the tile, i >= lag, signalling enabled
+        uint32_t can = 0;
+        if (!a.no_signal && base < nvalid) {
+            const uint32_t hi_q = min((uint32_t)W, nvalid - base);            // q < hi_q
+            const uint32_t lo_q = w0 + base >= lag ? 0u : min((uint32_t)W, lag - (w0 + base));  // q >= lo_q
+            can = ((1u << hi_q) - 1u) & ~((1u << lo_q) - 1u);
+        }
+        // per window three bits: sig (D - R > G), nos (R - D > G), dn (n*k < S1: sign bit of di).
+        // The S1 term of the guard band uses the thread's upper bound S1 + W*size (S1 grows by at
+        // most `size` per window): one conversion per thread instead of one per window.
+        uint32_t sigm = 0, nosm = 0, dnm = 0;
+        const float gconst = __builtin_fmaf(g1, (float)(S1 + (uint32_t)W * size), g0);
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            const uint32_t kout = (og[q >> 2] >> (8 * (q & 3))) & 0xFFu;
+            const uint32_t kin = (in[q >> 2] >> (8 * (q & 3))) & 0xFFu;
+            const uint32_t kk = (in[(q + 1) >> 2] >> (8 * ((q + 1) & 3))) & 0xFFu;
+            const int32_t di = (int32_t)__umul24(lag, kk) - (int32_t)S1;   // sign: side of the mean
+            const uint32_t V = __umul24(lag, S2) - __umul24(S1, S1);       // n*S2 - S1^2 >= 0
+            const float Df = fabsf((float)di);
+            const float Rf = thr_abs * __builtin_amdgcn_sqrtf(cvar * (float)V);
+            const float diff = Df - Rf;
+            const float G = __builtin_fmaf(g23, Df + Rf, gconst);
+            // one bit per test, shifted in MSB first: the sign bits of G - diff (diff > G),
+            // G + diff (diff < -G) and di; (acc << 1) | sign(x) is a single v_alignbit
+            sigm = __builtin_amdgcn_alignbit(sigm, __float_as_uint(G - diff), 31);
+            nosm = __builtin_amdgcn_alignbit(nosm, __float_as_uint(G + diff), 31);
+            dnm = __builtin_amdgcn_alignbit(dnm, (uint32_t)di, 31);
+            S1 += kin - kout;
+            S2 += __umul24(kin, kin) - __umul24(kout, kout);
+        }
+        // window q sits at bit W-1-q of the accumulators: flip to bit q
+        sigm = __brev(sigm) >> (32 - W);
+        nosm = __brev(nosm) >> (32 - W);
+        dnm = __brev(dnm) >> (32 - W);
+        if (!(g0 < INFINITY)) sigm = nosm = 0;   // non-finite / negative threshold: every window is exact
+        uint32_t decided = sigm | nosm;
+        crest = sigm & ~dnm;                     // D > R + G > 0, so di != 0 here
+        trough = sigm & dnm;
+        // Window i == lag averages windows [0,lag) (stat.rs:30-31) like i == lag+1, not
+        // [i-1-lag, i-1): its owner (one thread per ctg) redoes the integer decision with the
+        // sums over K[base+qlag+1, base+qlag+1+lag).
+        const uint32_t qlag = lag - (w0 + base);                             // wraps when i == lag is not here
+        if (qlag < (uint32_t)W) {
+            const uint32_t bit = 1u << qlag;
+            uint32_t s1 = 0, s2 = 0;
+            for (uint32_t j = 0; j < lag; ++j) {
+                const uint32_t kv = K[base + qlag + 1u + j];
+                s1 += kv;
+                s2 += kv * kv;
+            }
+            const uint32_t kk = K[base + qlag + lag + 1u];
+            const int32_t di = (int32_t)(lag * kk) - (int32_t)s1;
+            const uint32_t V = lag * s2 - s1 * s1;
+            const float Df = fabsf((float)di);
+            const float Rf = thr_abs * __builtin_amdgcn_sqrtf(cvar * (float)V);
+            const float diff = Df - Rf;
+            const float G = __builtin_fmaf(g1, (float)s1, __builtin_fmaf(g23, Df + Rf, g0));
+            decided = fabsf(diff) > G ? (decided | bit) : (decided & ~bit);
+            crest = (diff > 0.0f && di > 0) ? (crest | bit) : (crest & ~bit);
+            trough = (diff > 0.0f && di < 0) ? (trough | bit) : (trough & ~bit);
+        }
+        crest &= can & decided;
+        trough &= can & decided;
+        pend = can & ~decided;
+        // homopolymer / N runs: all lag averaged counts and the window's own count equal
+        // (V == 0 and D == 0, undecidable in integers): settled by the precomputed table.
+        // Tested on demand for pending windows only (rare), straight from K.
+        if (__ballot(pend != 0u)) {
+            uint32_t todo = pend;
+            while (todo) {
+                const int q = __ffs((int)todo) - 1;
+                todo &= todo - 1u;
+                const uint32_t i = w0 + base + (uint32_t)q;
+                const uint32_t tj = base + (uint32_t)q + (i == lag ? 1u : 0u);
+                const uint32_t kk = K[base + (uint32_t)q + lag + 1u];
+                bool same = true;
+                for (uint32_t j = 0; j < lag && same; ++j) same = K[tj + j] == kk;
+                if (same) {
+                    const int sg = a.const_sig[kk];
+                    pend &= ~(1u << q);
+                    crest |= sg > 0 ? 1u << q : 0u;
+                    trough |= sg < 0 ? 1u << q : 0u;
+                }
+            }
+        }
+    }
+    wave_stamp(a, 4);
+    // Guard-band windows: exact f32 order, one window at a time by the whole wave.
+    {
+        const uint32_t lane = tid & 63u;
+        unsigned long long bal = __ballot(pend != 0u);
+        uint32_t n_exact = 0;
+        while (bal) {
+            const int L = __ffsll(bal) - 1;                                   // wave-uniform
+            const uint32_t pL = (uint32_t)__builtin_amdgcn_readlane((int)pend, L);
+            const uint32_t q = (uint32_t)__ffs((int)pL) - 1u;
+            const uint32_t baseL = ((tid & ~63u) + (uint32_t)L) * (uint32_t)W;
+            const uint32_t first = (w0 + baseL + q == lag) ? 1u : 0u;
+            const int sg = exact_signal_wave(K, baseL + q + first, baseL + q + lag + 1u, lag, a.fsize, a.thr);
+            if (lane == (uint32_t)L) {
+                pend &= ~(1u << q);
+                crest |= sg > 0 ? 1u << q : 0u;
+                trough |= sg < 0 ? 1u << q : 0u;
+            }
+            ++n_exact;
+            bal = __ballot(pend != 0u);
+        }
+        if (n_exact && lane == 0)
+            atomicAdd(&a.counters[(blockIdx.x & (kShards - 1u)) * kShardWords + 1u], (unsigned long long)n_exact);
+    }
+
+    wave_stamp(a, 5);
+    // ---- phase 4a: dense rows, coalesced through LDS -------------------------
+    if (want_dense) {
+        if (base < nvalid) {
+#pragma unroll
+            for (int q = 0; q < W; ++q)
+                SG[base + q] = (uint8_t)(((crest >> q) & 1u) | (((trough >> q) & 1u) ? 0xFFu : 0u));
+        }
+        __syncthreads();
+        for (uint32_t idx = tid; idx < nvalid; idx += 256u) {
+            a.dense_cnt[cg.win_base + w0 + idx] = K[idx + lag + 1u];
+            a.dense_sig[cg.win_base + w0 + idx] = (int8_t)SG[idx];
+        }
+    }
+
+    // ---- phase 4b: ordered compaction: thread order == window order ----------
+    if (want_peaks) {
+        const uint32_t both = crest | trough;
+        const uint32_t mine = (uint32_t)__popc(both);
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_256<uint32_t>(mine, scr, tot);
+        if (tid == 0) a.tile_cnt[blockIdx.x] = tot;
+        if (mine) {
+            gams_peak_t *const region = a.peaks + (size_t)blockIdx.x * a.tile_cap;
+            uint32_t pos = ex;
+            uint32_t bits = both;
+            while (bits) {
+                const int q = __ffs((int)bits) - 1;
+                bits &= bits - 1u;
+                const uint32_t code = (crest >> q) & 1u;
+                if (pos < a.tile_cap) {
+                    gams_peak_t pk;
+                    pk.ctg = tl.ctg;
+                    pk.window = w0 + base + (uint32_t)q;
+                    pk.gc_count = K[base + (uint32_t)q + lag + 1u];
+                    pk.signal = code == 1u ? 1 : -1;
+                    region[pos] = pk;
+                }
+                ++pos;
+            }
+        }
+    }
+    wave_stamp(a, 6);
+}
+
+// ---- influence != 1: the filtered[] recurrence is serial per ctg -------------
+// One lane per ctg, the reference's loop verbatim (stat.rs:16-56) over the dense
+// gc counts a counts-only pass of wave_tile_kernel left in HBM.  `ring` holds
+// filtered[] for the ctg (n_win floats, written once, read lag times).
+__global__ void wave_serial_kernel(const WaveCtgDev *ctgs, uint32_t n_ctg, const uint32_t *dense_cnt,
+                                   int8_t *dense_sig, float *filtered, uint32_t lag, float thr,
+                                   float influence, float fsize) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_ctg) return;
+    const WaveCtgDev cg = ctgs[c];
+    const uint32_t n = cg.n_win;
+    const uint32_t *k = dense_cnt + cg.win_base;
+    int8_t *sig = dense_sig + cg.win_base;
+    float *f = filtered + cg.win_base;
+    const float len = (float)lag;
+    for (uint32_t i = 0; i < n; ++i) {
+        f[i] = (float)k[i] / fsize;   // filtered_data = data.to_owned()  (stat.rs:21)
+        sig[i] = 0;
+    }
+    if (n < lag || lag == 0) return;
+    float avg, sd;
+    {
+        float sum = 0.0f;
+        for (uint32_t q = 0; q < lag; ++q) sum = sum + f[q];
+        avg = sum / len;
+        float sq = 0.0f;
+        for (uint32_t q = 0; q < lag; ++q) {
+            const float d = f[q] - avg;
+            sq = sq + d * d;
+        }
+        sd = sqrtf(sq / (len - 1.0f));
+    }
+    for (uint32_t i = lag; i < n; ++i) {
+        const float x = (float)k[i] / fsize;
+        if (fabsf(x - avg) > thr * sd) {                               // stat.rs:36
+            sig[i] = x > avg ? 1 : -1;
+            const float a = influence * x;
+            const float b = (1.0f - influence) * f[i - 1];
+            f[i] = a + b;                                              // stat.rs:42
+        } else {
+            f[i] = x;
+        }
+        float sum = 0.0f;
+        for (uint32_t q = i - lag; q < i; ++q) sum = sum + f[q];       // stat.rs:51
+        avg = sum / len;
+        float sq = 0.0f;
+        for (uint32_t q = i - lag; q < i; ++q) {                       // stat.rs:52
+            const float d = f[q] - avg;
+            sq = sq + d * d;
+        }
+        sd = sqrtf(sq / (len - 1.0f));
+    }
+}
+
+// Ordered compaction of dense signals (serial path): same tile/offset scheme as
+// phase 4 of wave_tile_kernel.
+__global__ __launch_bounds__(256) void wave_compact_kernel(const WaveCtgDev *ctgs, const WaveTile *tiles,
+                                                            uint32_t tw, const uint32_t *dense_cnt,
+                                                            const int8_t *dense_sig, gams_peak_t *peaks,
+                                                            uint32_t tile_cap, uint32_t *tile_cnt) {
+    __shared__ uint32_t PC[132];
+    __shared__ uint64_t scr[8];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const WaveTile tl = tiles[blockIdx.x];
+    const struct { uint64_t win_base; uint32_t n_win; } cg = {tl.win_base, tl.n_win};
+    const uint32_t w0 = tl.w0, w1 = min(w0 + tw, cg.n_win);
+    const uint32_t R = tw >> 8;
+    uint64_t sigbits = 0;
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t i = w0 + (r << 8) + tid;
+        int sg = 0;
+        if (i < w1) sg = dense_sig[cg.win_base + i];
+        const unsigned long long bal = __ballot(sg != 0);
+        if (lane == 0) PC[(r << 2) + wv] = (uint32_t)__popcll(bal);
+        sigbits |= (uint64_t)(sg & 3) << (2u * r);
+    }
+    __syncthreads();
+    const uint32_t ncell = R << 2;
+    const uint32_t mine = tid < ncell ? PC[tid] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan_256<uint32_t>(mine, reinterpret_cast<uint32_t *>(scr), tot);
+    if (tid < ncell) PC[tid] = ex;
+    if (tid == 0) tile_cnt[blockIdx.x] = tot;
+    const uint32_t base = 0;
+    if (!tot) return;
+    peaks += (size_t)blockIdx.x * tile_cap;
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t code = (uint32_t)(sigbits >> (2u * r)) & 3u;
+        const unsigned long long bal = __ballot(code != 0);
+        if (code) {
+            const uint32_t i = w0 + (r << 8) + tid;
+            const uint32_t pos = base + PC[(r << 2) + wv] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (pos < tile_cap) {
+                gams_peak_t pk;
+                pk.ctg = tl.ctg;
+                pk.window = i;
+                pk.gc_count = dense_cnt[cg.win_base + i];
+                pk.signal = code == 1u ? 1 : -1;
+                peaks[pos] = pk;
+            }
+        }
+    }
+}
+
+// Exclusive prefix of the per-tile peak counts -> tile_off; totals[0] = all peaks, totals[1] = the
+// fullest tile.  One workgroup of 1024 lanes, each summing a contiguous run of tiles.
+__global__ __launch_bounds__(1024) void wave_offsets_kernel(const uint32_t *tile_cnt, uint32_t nt,
+                                                            unsigned long long *tile_off,
+                                                            unsigned long long *totals) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ uint32_t wmax[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t per = (nt + 1023u) / 1024u;
+    const uint32_t t0 = min(nt, tid * per), t1 = min(nt, t0 + per);
+    unsigned long long mine = 0;
+    uint32_t mx = 0;
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t c = tile_cnt[t];
+        mine += c;
+        mx = max(mx, c);
+    }
+    unsigned long long inc = wave_incl_scan_u64(mine);
+    for (int d = 32; d; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    if (lane == 63) wsum[wv] = inc;
+    if (lane == 0) wmax[wv] = mx;
+    __syncthreads();
+    unsigned long long base = 0, all = 0;
+    uint32_t worst = 0;
+    for (uint32_t w = 0; w < 16; ++w) {
+        if (w < wv) base += wsum[w];
+        all += wsum[w];
+        worst = max(worst, wmax[w]);
+    }
+    unsigned long long off = base + inc - mine;
+    for (uint32_t t = t0; t < t1; ++t) {
+        tile_off[t] = off;
+        off += tile_cnt[t];
+    }
+    if (tid == 0) {
+        totals[0] = all;
+        totals[1] = worst;
+    }
+}
+
+// Pack the per-tile slots into one dense, (ctg, window)-ordered array: one wave per tile.  A tile
+// that would not fit `cap` records (or overflowed its slot) is skipped: the host regrows and repeats.
+__global__ __launch_bounds__(64) void wave_gather_kernel(const gams_peak_t *slots, uint32_t tile_cap,
+                                                         const uint32_t *tile_cnt, const unsigned long long *tile_off,
+                                                         gams_peak_t *dense, unsigned long long cap) {
+    const uint32_t t = blockIdx.x;
+    const uint32_t n = tile_cnt[t];
+    const unsigned long long o = tile_off[t];
+    if (n > tile_cap || o + n > cap) return;
+    const gams_peak_t *src = slots + (size_t)t * tile_cap;
+    gams_peak_t *dst = dense + o;
+    for (uint32_t i = threadIdx.x; i < n; i += 64u) dst[i] = src[i];
+}
+
+}  // namespace

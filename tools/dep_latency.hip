@@ -25,7 +25,7 @@ __device__ __forceinline__ float seq_add_lanes(float carry, float x, uint32_t m)
     }
     return carry;
 }
-// the exact path as wave.hip has it today
+// the exact path as it was before (row-DPP recurrence)
 __device__ __noinline__ float exact_dpp(const uint8_t *K, uint32_t tj, uint32_t n, float fsize) {
     const uint32_t lane = threadIdx.x & 63u;
     const float len = (float)n;
