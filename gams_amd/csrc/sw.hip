@@ -177,6 +177,12 @@ __device__ __forceinline__ float range_gc(const SwArgs &a, int32_t s, int32_t e)
     return (float)(uint32_t)c / flen;
 }
 
+// G/C bases in front of ctg byte offset b (clamped into the ctg like range_gc)
+__device__ __forceinline__ uint64_t gc_prefix_at(const SwArgs &a, int64_t b) {
+    b = b < 0 ? 0 : (b > a.len ? a.len : b);
+    return gc_before(a.pm, a.seg, a.seq_off + (uint64_t)b);
+}
+
 // one thread per (feature, slot); slot 0 = M, 1..max = L, max+1..2max = R
 __global__ __launch_bounds__(256) void sw_kernel(const SwArgs a) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -221,18 +227,42 @@ __global__ __launch_bounds__(256) void sw_kernel(const SwArgs a) {
     const int32_t flen = re - rs + 1;
     const int32_t nt = flen >= a.size ? (flen - a.size) / a.size + 1 : 0;  // sliding(range,size,size)
     const float len = (float)nt;
+    // Consecutive tiles share a boundary: one prefix lookup per boundary (nt + 1) instead of two
+    // per tile and pass; the tile values are kept for the second pass when they fit.
+    constexpr int kKeep = 8;
+    float xs[kKeep];
     float sum = 0.0f;
-    for (int32_t t = 0; t < nt; ++t) {
-        const int32_t ts = rs + t * a.size;
-        sum = sum + round4(range_gc(a, ts, ts + a.size - 1));           // stat.rs:3
+    {
+        uint64_t before = gc_prefix_at(a, (int64_t)rs - a.chr_start);
+#pragma unroll   // constant indices keep xs[] in registers
+        for (int32_t t = 0; t < kKeep; ++t) {
+            if (t < nt) {
+                const uint64_t upto = gc_prefix_at(a, (int64_t)rs - a.chr_start + (int64_t)(t + 1) * a.size);
+                xs[t] = round4((float)(uint32_t)(upto - before) / (float)a.size);
+                before = upto;
+                sum = sum + xs[t];                                          // stat.rs:3
+            }
+        }
+        for (int32_t t = kKeep; t < nt; ++t) {
+            const uint64_t upto = gc_prefix_at(a, (int64_t)rs - a.chr_start + (int64_t)(t + 1) * a.size);
+            sum = sum + round4((float)(uint32_t)(upto - before) / (float)a.size);
+            before = upto;
+        }
     }
     const float mean = sum / len;                                       // stat.rs:5
     float sq = 0.0f;
-    for (int32_t t = 0; t < nt; ++t) {
+#pragma unroll
+    for (int32_t t = 0; t < kKeep; ++t) {
+        if (t < nt) {
+            const float d = xs[t] - mean;
+            sq = sq + d * d;                                                // stat.rs:12
+        }
+    }
+    for (int32_t t = kKeep; t < nt; ++t) {
         const int32_t ts = rs + t * a.size;
         const float x = round4(range_gc(a, ts, ts + a.size - 1));
         const float d = x - mean;
-        sq = sq + d * d;                                                // stat.rs:12
+        sq = sq + d * d;
     }
     const float sd = sqrtf(sq / (len - 1.0f));                          // stat.rs:13
     float cv;                                                           // utils.rs:169-175
