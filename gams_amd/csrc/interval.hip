@@ -40,11 +40,21 @@ struct KeyDir {
 };
 
 // everything a query needs to know about its group, one 48-B record (one or two lines)
+struct IvRec {
+    uint32_t start, stop;
+    uint64_t orig;
+};
+
 struct IndexGroup {
     uint64_t off;     // first interval of the group
     uint32_t n;       // intervals in the group
     uint32_t maxlen;  // max(stop - start), Lapper::max_len
     KeyDir start, stop;
+};
+
+struct SpanRec {
+    int32_t lo, hi;   // inclusive
+    uint64_t cum;     // covered bases in the group's spans before this one
 };
 
 struct SpanGroup {
@@ -59,9 +69,8 @@ struct gams_index {
     uint64_t m = 0;
     IndexGroup *d_groups = nullptr;
     uint32_t *d_stops = nullptr;     // per group, ascending, sorted independently (for count)
-    uint32_t *d_lstart = nullptr;    // per group, (start,stop)-sorted pairs; the starts alone are ascending
-    uint32_t *d_lstop = nullptr;
-    uint64_t *d_lorig = nullptr;     // caller's index of each sorted pair
+    uint32_t *d_lstart = nullptr;    // per group, starts of the (start,stop)-sorted pairs: ascending (both searches)
+    IvRec *d_lrec = nullptr;         // the sorted pairs + the caller's index of each, 16 B (locate's scan)
     uint32_t *d_dir_start = nullptr; // m + n_groups entries: group g's directory begins at off[g] + g
     uint32_t *d_dir_stop = nullptr;
 };
@@ -70,8 +79,7 @@ struct gams_spans {
     uint32_t n_groups = 0;
     uint64_t m = 0;
     SpanGroup *d_groups = nullptr;
-    int32_t *d_lo = nullptr, *d_hi = nullptr;
-    uint64_t *d_cum = nullptr;       // covered bases in the group's spans before span i
+    SpanRec *d_rec = nullptr;        // one 16-B record per span: the search and its two follow-up reads share a line
     uint32_t *d_dir_lo = nullptr;
 };
 
@@ -116,10 +124,10 @@ __global__ __launch_bounds__(256) void interval_count_kernel(const IndexGroup *g
 }
 
 __global__ __launch_bounds__(256) void interval_locate_kernel(const IndexGroup *groups, const uint32_t *lstart,
-                                                              const uint32_t *lstop, const uint64_t *lorig,
-                                                              const uint32_t *dir_start, uint32_t n_groups,
-                                                              const uint32_t *group, const uint32_t *qs,
-                                                              const uint32_t *qe, uint64_t nq, int64_t *out) {
+                                                              const IvRec *lrec, const uint32_t *dir_start,
+                                                              uint32_t n_groups, const uint32_t *group,
+                                                              const uint32_t *qs, const uint32_t *qe, uint64_t nq,
+                                                              int64_t *out) {
     const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const uint32_t g = group[q];
@@ -132,32 +140,48 @@ __global__ __launch_bounds__(256) void interval_locate_kernel(const IndexGroup *
         const uint64_t hi = G.off + G.n;
         for (uint64_t i = G.off + dir_lower_bound<0u>(lstart + G.off, dir_start + G.off + g, G.n, G.start, from);
              i < hi; ++i) {
-            const uint32_t is = lstart[i];
-            if (is < e && lstop[i] > s) {  // Interval::overlap
-                hit = (int64_t)lorig[i];
+            const IvRec r = lrec[i];
+            if (r.start < e && r.stop > s) {  // Interval::overlap
+                hit = (int64_t)r.orig;
                 break;
             }
-            if (is >= e) break;
+            if (r.start >= e) break;
         }
     }
     out[q] = hit;
 }
 
 // covered positions <= x inside the group's spans
-__device__ __forceinline__ uint64_t covered_upto(const int32_t *slo, const int32_t *shi, const uint64_t *cum,
-                                                 const uint32_t *dir, const SpanGroup &G, uint32_t g, int32_t x) {
-    // spans with lo <= x = keys < x+1 in biased order
-    const uint32_t i = dir_lower_bound<0x80000000u>(reinterpret_cast<const uint32_t *>(slo) + G.off,
-                                                    dir + G.off + g, G.n, G.lo,
-                                                    (uint64_t)((uint32_t)x ^ 0x80000000u) + 1u);
+__device__ __forceinline__ uint64_t covered_upto(const SpanRec *rec, const uint32_t *dir, const SpanGroup &G,
+                                                 uint32_t g, int32_t x) {
+    // spans with lo <= x = keys < x+1 in biased order; directory lookup, then a search over rec[].lo
+    const SpanRec *r = rec + G.off;
+    uint32_t i = 0;
+    const uint64_t key = (uint64_t)((uint32_t)x ^ 0x80000000u) + 1u;
+    if (G.n != 0 && key > (uint64_t)G.lo.key0) {
+        const uint64_t b = (key - G.lo.key0) >> G.lo.shift;
+        if (b >= G.lo.nb) {
+            i = G.n;
+        } else {
+            const uint32_t *d = dir + G.off + g;
+            uint32_t lo = d[b], hi = d[b + 1];
+            while (lo < hi) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if ((uint64_t)((uint32_t)r[mid].lo ^ 0x80000000u) < key)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            i = lo;
+        }
+    }
     if (i == 0) return 0;
-    const uint64_t j = G.off + i - 1;
-    const int32_t top = shi[j] < x ? shi[j] : x;
-    return cum[j] + (uint64_t)((int64_t)top - slo[j] + 1);
+    const SpanRec s = r[i - 1];
+    const int32_t top = s.hi < x ? s.hi : x;
+    return s.cum + (uint64_t)((int64_t)top - s.lo + 1);
 }
 
-__global__ __launch_bounds__(256) void span_cover_kernel(const SpanGroup *groups, const int32_t *slo,
-                                                         const int32_t *shi, const uint64_t *cum,
+__global__ __launch_bounds__(256) void span_cover_kernel(const SpanGroup *groups, const SpanRec *rec,
                                                          const uint32_t *dir, uint32_t n_groups,
                                                          const uint32_t *group, const int32_t *clip_lo,
                                                          const int32_t *clip_hi, const int32_t *qs,
@@ -173,8 +197,8 @@ __global__ __launch_bounds__(256) void span_cover_kernel(const SpanGroup *groups
         uint64_t card = 0;
         if (H >= L) {
             const SpanGroup G = groups[g];
-            const uint64_t upto_h = covered_upto(slo, shi, cum, dir, G, g, H);
-            const uint64_t upto_l = L > INT32_MIN ? covered_upto(slo, shi, cum, dir, G, g, L - 1) : 0;
+            const uint64_t upto_h = covered_upto(rec, dir, G, g, H);
+            const uint64_t upto_l = L > INT32_MIN ? covered_upto(rec, dir, G, g, L - 1) : 0;
             card = upto_h - upto_l;
         }
         const int32_t total = (int32_t)((int64_t)e - s + 1);
@@ -261,7 +285,8 @@ int gams_index_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
             return gams_fail(h, GAMS_EUNSUPPORTED, "index_create: a group holds more than 2^32-16 intervals");
     GAMS_HIP(h, hipSetDevice(h->device));
     // Lapper::new: intervals.sort() by (start, stop); stops also sorted on their own
-    std::vector<uint32_t> tt(stops, stops + m), ls(m), lt(m);
+    std::vector<uint32_t> tt(stops, stops + m), ls(m);
+    std::vector<IvRec> lrec(m);
     std::vector<uint32_t> dir_s(m + n_groups + 1), dir_t(m + n_groups + 1);
     std::vector<uint64_t> perm(m);
     std::vector<IndexGroup> groups(std::max<uint32_t>(n_groups, 1));
@@ -275,8 +300,8 @@ int gams_index_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
         uint32_t ml = 0;
         for (uint64_t i = lo; i < hi; ++i) {
             ls[i] = starts[perm[i]];
-            lt[i] = stops[perm[i]];
-            if (lt[i] > ls[i]) ml = std::max(ml, lt[i] - ls[i]);
+            lrec[i] = IvRec{ls[i], stops[perm[i]], perm[i]};
+            if (lrec[i].stop > ls[i]) ml = std::max(ml, lrec[i].stop - ls[i]);
         }
         IndexGroup &G = groups[g];
         G.off = lo;
@@ -291,8 +316,7 @@ int gams_index_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
     hipError_t e = to_device(&ix->d_groups, groups.data(), groups.size());
     if (e == hipSuccess) e = to_device(&ix->d_stops, tt.data(), m);
     if (e == hipSuccess) e = to_device(&ix->d_lstart, ls.data(), m);
-    if (e == hipSuccess) e = to_device(&ix->d_lstop, lt.data(), m);
-    if (e == hipSuccess) e = to_device(&ix->d_lorig, perm.data(), m);
+    if (e == hipSuccess) e = to_device(&ix->d_lrec, lrec.data(), m);
     if (e == hipSuccess) e = to_device(&ix->d_dir_start, dir_s.data(), dir_s.size());
     if (e == hipSuccess) e = to_device(&ix->d_dir_stop, dir_t.data(), dir_t.size());
     if (e != hipSuccess) {
@@ -313,8 +337,7 @@ void gams_index_destroy(gams_gpu_t *h, gams_index_t *ix) {
     (void)hipFree(ix->d_groups);
     (void)hipFree(ix->d_stops);
     (void)hipFree(ix->d_lstart);
-    (void)hipFree(ix->d_lstop);
-    (void)hipFree(ix->d_lorig);
+    (void)hipFree(ix->d_lrec);
     (void)hipFree(ix->d_dir_start);
     (void)hipFree(ix->d_dir_stop);
     delete ix;
@@ -369,8 +392,8 @@ int gams_gpu_locate(gams_gpu_t *h, gams_index_t *ix, const uint32_t *group, cons
     Q_HIP(qb.in(&d_o, (const int64_t *)nullptr, nq, h->compute));
     Q_HIP(hipEventRecord(h->k0, h->compute));
     hipLaunchKernelGGL(interval_locate_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->compute,
-                       ix->d_groups, ix->d_lstart, ix->d_lstop, ix->d_lorig, ix->d_dir_start, ix->n_groups, d_g,
-                       d_s, d_e, nq, d_o);
+                       ix->d_groups, ix->d_lstart, ix->d_lrec, ix->d_dir_start, ix->n_groups, d_g, d_s, d_e, nq,
+                       d_o);
     Q_HIP(hipGetLastError());
     Q_HIP(hipEventRecord(h->k1, h->compute));
     h->k_valid = true;
@@ -384,7 +407,7 @@ int gams_spans_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
     if (!h || !out || !group_off) return gams_fail(h, GAMS_EINVAL, "spans_create: null argument");
     const uint64_t m = group_off[n_groups];
     if (m && (!lo || !hi)) return gams_fail(h, GAMS_EINVAL, "spans_create: null span arrays");
-    std::vector<uint64_t> cum(m);
+    std::vector<SpanRec> rec(m);
     for (uint32_t g = 0; g < n_groups; ++g) {
         if (group_off[g] > group_off[g + 1]) return gams_fail(h, GAMS_EINVAL, "spans_create: group_off not ascending");
         if (group_off[g + 1] - group_off[g] > 0xfffffff0ull)
@@ -393,7 +416,7 @@ int gams_spans_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
         for (uint64_t i = group_off[g]; i < group_off[g + 1]; ++i) {
             if (hi[i] < lo[i] || (i > group_off[g] && lo[i] <= hi[i - 1]))
                 return gams_fail(h, GAMS_EINVAL, "spans_create: spans must be sorted and disjoint");
-            cum[i] = c;
+            rec[i] = SpanRec{lo[i], hi[i], c};
             c += (uint64_t)((int64_t)hi[i] - lo[i] + 1);
         }
     }
@@ -413,9 +436,7 @@ int gams_spans_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
     sp->n_groups = n_groups;
     sp->m = m;
     hipError_t e = to_device(&sp->d_groups, groups.data(), groups.size());
-    if (e == hipSuccess) e = to_device(&sp->d_lo, lo, m);
-    if (e == hipSuccess) e = to_device(&sp->d_hi, hi, m);
-    if (e == hipSuccess) e = to_device(&sp->d_cum, cum.data(), m);
+    if (e == hipSuccess) e = to_device(&sp->d_rec, rec.data(), m);
     if (e == hipSuccess) e = to_device(&sp->d_dir_lo, dir.data(), dir.size());
     if (e != hipSuccess) {
         gams_spans_destroy(h, sp);
@@ -434,9 +455,7 @@ void gams_spans_destroy(gams_gpu_t *h, gams_spans_t *sp) {
     }
     (void)hipFree(sp->d_groups);
     (void)hipFree(sp->d_dir_lo);
-    (void)hipFree(sp->d_lo);
-    (void)hipFree(sp->d_hi);
-    (void)hipFree(sp->d_cum);
+    (void)hipFree(sp->d_rec);
     delete sp;
 }
 
@@ -459,8 +478,7 @@ int gams_gpu_cover(gams_gpu_t *h, gams_spans_t *sp, const uint32_t *group, const
     Q_HIP(qb.in(&d_o, (const float *)nullptr, nq, h->compute));
     Q_HIP(hipEventRecord(h->k0, h->compute));
     hipLaunchKernelGGL(span_cover_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->compute,
-                       sp->d_groups, sp->d_lo, sp->d_hi, sp->d_cum, sp->d_dir_lo, sp->n_groups, d_g, d_cl, d_ch,
-                       d_s, d_e, nq, d_o);
+                       sp->d_groups, sp->d_rec, sp->d_dir_lo, sp->n_groups, d_g, d_cl, d_ch, d_s, d_e, nq, d_o);
     Q_HIP(hipGetLastError());
     Q_HIP(hipEventRecord(h->k1, h->compute));
     h->k_valid = true;
