@@ -98,3 +98,15 @@ for _ in range(2):
 ms = kernel_ms()
 print(f"anno cover: {nq / ms / 1e6:.2f} G lines/s, {nq * 16 / ms / 1e6:.1f} GB/s at 16 B/line ({ms:.3f} ms)")
 lib.gams_spans_destroy(eng.h, sp)
+
+# ---- call-level (host arrays in, host array out) rate of the query kernels ----
+ix = C.c_void_p()
+eng.check(lib.gams_index_create(eng.h, n_ctg, off.ctypes.data, starts.ctypes.data, stops.ctypes.data, C.byref(ix)))
+best = 1e9
+for _ in range(3):
+    t0 = time.perf_counter()
+    eng.check(lib.gams_gpu_count(eng.h, ix, qg.ctypes.data, qs.ctypes.data, qe.ctypes.data, nq, out.ctypes.data))
+    best = min(best, time.perf_counter() - t0)
+print(f"count, whole call with host arrays ({nq} queries): {best * 1e3:.2f} ms -> {nq / best / 1e9:.2f} G queries/s, "
+      f"{nq * 16 / best / 1e9:.1f} GB/s over PCIe")
+lib.gams_index_destroy(eng.h, ix)
