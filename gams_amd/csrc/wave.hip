@@ -612,6 +612,14 @@ struct Launcher {
     int rc = GAMS_OK;
 };
 
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+
 static int wave_queue_parity(gams_gpu_t *h, gams_wave_plan_t *p, uint64_t first, uint32_t rest, uint32_t parity) {
     for (uint32_t j = 0; j < rest; ++j) {
         const uint32_t k = (uint32_t)((first + j) % p->depth);
@@ -631,7 +639,7 @@ static void wave_launcher_main(Launcher *L, int device) {
         L->armed = false;
         lk.unlock();
         int g;
-        while ((g = L->go.load(std::memory_order_acquire)) == 0) __builtin_ia32_pause();
+        while ((g = L->go.load(std::memory_order_acquire)) == 0) cpu_relax();   // a few microseconds
         int rc = GAMS_OK;
         if (g == 1) rc = bound ? wave_queue_parity(L->h, L->p, L->first, L->rest, 1u) : GAMS_EHIP;
         lk.lock();
