@@ -307,8 +307,9 @@ __global__ __launch_bounds__(256) void wave_tile_kernel(const WaveArgs a) {
 // v_readlane (the compiler's single-SGPR version needs an s_nop 1 per element).
 // Cycles per lag-100 evaluation, alone on a SIMD (tools/dep_latency.hip): 2349, against 4952
 // for the row-DPP chain (s_nop 1 + v_add_f32_dpp row_shr:1 per element) this replaced and
-// 3733 for the single-SGPR form.  Inside the S288c launch an evaluation still costs ~4.9k
-// cycles (5.7k before): the code runs a few dozen times per launch, each time cold on its CU.
+// 3733 for the single-SGPR form; a cold first execution on a CU adds ~180 cycles.  The phase
+// stamps of the S288c launch show ~4.9k cycles (5.7k before), the stamping wave's wait for its
+// own stamp stores included.
 // Tried and dropped: terms through LDS with broadcast ds_read_b128 + VGPR adds (8.4k cycles in
 // the kernel: the loop control eats the shorter chain), and inlining everything (scratch
 // spills under the 64-VGPR cap, 8.2 -> 11.7 us per launch).
