@@ -90,6 +90,7 @@ struct gams_wave_plan {
     gams_peak_t *h_peaks = nullptr;             // pinned: packed peaks of the last gams_wave_peaks
     size_t h_peaks_bytes = 0;
     uint32_t tile_cap = 0, tile_cap_req = 0;
+    uint32_t tw_req = 0;                        // gams_wave_plan_set_tile request (0: the library's choice)
     gams_peak_t *d_dense = nullptr;             // packed copy made by gams_wave_peaks
     uint64_t dense_cap = 0;
     uint64_t run_idx = 0;
@@ -183,13 +184,18 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
                 if (tw_req == tw) pick = w;
                 continue;
             }
-            // default: W = 12 once that still gives >= 4 tiles per CU, else W = 4 (more, shorter
-            // workgroups: a small genome is launch-latency bound).  W = 20 for the baked step-1
+            // default: W = 12 once that gives enough tiles, else W = 4 (more, shorter workgroups: a
+            // small genome is launch-latency bound).  Measured per pass, W = 4 / W = 12, one pass at
+            // a time and four in flight: 1.2 M windows (399 tiles of W = 12) 8.1 / 9.3 us and
+            // 3.3 / 3.1 us; 2.4 M (791) 11.5 / 11.4 and 6.4 / 4.6; 3.6 M (1187) 15.0 / 14.5 and
+            // 9.3 / 6.7 -- with passes in flight the W = 12 kernel's lower instruction count per
+            // window decides (5.3e11 against 3.8e11 windows/s).  W = 20 for the baked step-1
             // kernel (measured 452 vs 503 us on 3.8e8 windows), otherwise only on request.
             const uint64_t tiles = p->total_windows / tw;
             const bool step1 = q.size == 100 && q.step == 1 && q.lag == 100;   // baked W = 20 fits 64 VGPRs
+            const uint64_t enough12 = p->depth >= 2 ? 512 : 640;
             if (pick == 0 && w == 20 && step1 && tiles >= 1024) pick = w;
-            if (pick == 0 && w == 12 && tiles >= 1024) pick = w;
+            if (pick == 0 && w == 12 && tiles >= enough12) pick = w;
             if (pick == 0 && w == 4) pick = w;
         }
         if (pick) {
@@ -471,6 +477,7 @@ int gams_wave_plan_set_tile(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tile_wi
     if (rc != GAMS_OK) return rc;
     rc = wave_build_geometry(h, p, tile_windows);
     if (rc != GAMS_OK) return rc;
+    p->tw_req = tile_windows;
     p->ran = false;
     (void)hipFree(p->d_stamps);
     p->d_stamps = nullptr;
@@ -726,6 +733,10 @@ int gams_wave_plan_set_depth(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t depth)
     p->run_idx = 0;
     p->last_way = 0;
     p->sel_age = 0;
+    rc = wave_build_geometry(h, p, p->tw_req);      // the default tile depends on the depth
+    if (rc != GAMS_OK) return rc;
+    (void)hipFree(p->d_stamps);                     // sized for the old tiling
+    p->d_stamps = nullptr;
     rc = wave_upload_geometry(h, p);
     if (rc == GAMS_OK) rc = wave_alloc_ways(h, p);
     return rc;
