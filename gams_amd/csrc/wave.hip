@@ -102,7 +102,7 @@ struct gams_wave_plan {
     uint8_t *arena_fixed = nullptr, *arena_geom = nullptr;
     size_t arena_fixed_bytes = 0, arena_geom_bytes = 0;
     bool ran = false;
-    struct Launcher *launcher = nullptr;   // second host thread of gams_wave_run_n (made on first use)
+    struct Launcher *launcher[gams_gpu::kMaxWays - 1] = {};   // extra queueing threads of gams_wave_run_n (made on first use)
     bool pipelined = false;       // gams_wave_plan_set_pipelined: an event per run; readers wait on it
     bool attr_set = false;        // dynamic-LDS attribute applied for the current geometry
     float g0 = 0, g1 = 0, g2 = 0, g3 = 0;
@@ -606,6 +606,9 @@ int gams_wave_run(gams_gpu_t *h, gams_wave_plan_t *p) {
 // The second queueing thread of gams_wave_run_n.  It lives as long as the plan (binding a new host
 // thread to the device costs ~100 us, more than a short batch), sleeps between batches and, once
 // armed, spins until the caller has queued the first round.
+// A queueing thread of gams_wave_run_n.  It lives as long as the plan (binding a new host thread
+// to the device costs ~100 us, more than a short batch), sleeps between batches and, once armed,
+// spins until the caller has queued the first round.
 struct Launcher {
     std::thread th;
     std::mutex mu;
@@ -616,6 +619,7 @@ struct Launcher {
     gams_wave_plan_t *p = nullptr;
     uint64_t first = 0;
     uint32_t rest = 0;
+    uint32_t share = 0, shares = 1;    // this thread queues the ways k with k % shares == share
     int rc = GAMS_OK;
 };
 
@@ -627,10 +631,12 @@ static inline void cpu_relax() {
 #endif
 }
 
-static int wave_queue_parity(gams_gpu_t *h, gams_wave_plan_t *p, uint64_t first, uint32_t rest, uint32_t parity) {
+// passes first .. first+rest-1 whose way belongs to `share` (way order is kept per way)
+static int wave_queue_share(gams_gpu_t *h, gams_wave_plan_t *p, uint64_t first, uint32_t rest, uint32_t share,
+                            uint32_t shares) {
     for (uint32_t j = 0; j < rest; ++j) {
         const uint32_t k = (uint32_t)((first + j) % p->depth);
-        if ((k & 1u) != parity) continue;
+        if (k % shares != share) continue;
         const int rc = wave_pass_on_way(h, p, k);
         if (rc != GAMS_OK) return rc;
     }
@@ -648,7 +654,7 @@ static void wave_launcher_main(Launcher *L, int device) {
         int g;
         while ((g = L->go.load(std::memory_order_acquire)) == 0) cpu_relax();   // a few microseconds
         int rc = GAMS_OK;
-        if (g == 1) rc = bound ? wave_queue_parity(L->h, L->p, L->first, L->rest, 1u) : GAMS_EHIP;
+        if (g == 1) rc = bound ? wave_queue_share(L->h, L->p, L->first, L->rest, L->share, L->shares) : GAMS_EHIP;
         lk.lock();
         L->rc = rc;
         L->finished = true;
@@ -657,25 +663,34 @@ static void wave_launcher_main(Launcher *L, int device) {
 }
 
 static void wave_launcher_stop(gams_wave_plan_t *p) {
-    Launcher *L = p->launcher;
-    if (!L) return;
-    {
-        std::lock_guard<std::mutex> lk(L->mu);
-        L->quit = true;
+    for (Launcher *&L : p->launcher) {
+        if (!L) continue;
+        {
+            std::lock_guard<std::mutex> lk(L->mu);
+            L->quit = true;
+        }
+        L->cv.notify_all();
+        L->th.join();
+        delete L;
+        L = nullptr;
     }
-    L->cv.notify_all();
-    L->th.join();
-    delete L;
-    p->launcher = nullptr;
 }
 
 int gams_wave_run_n(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t n) {
     if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_run_n: null argument");
     // One host thread queues a pass every ~3.3 us (hipLaunchKernelGGL); with three or four passes
     // in flight that is slower than the device drains them (2.85 us per 12-Mb pass), so a batch is
-    // queued by two threads, each owning the ways of one parity.  The first round goes through
-    // gams_wave_run on the caller: it applies the kernel attribute and the first-use stream waits.
-    const bool threaded = p->depth >= 3 && n >= 4 * p->depth;
+    // queued by several threads: the caller keeps way 0, launcher threads take the other ways
+    // (K = 1000 passes at depth 4: 4.4 / 3.1 / 3.0 / 3.0 us per pass with 1 / 2 / 3 / 4 threads;
+    // K = 200: 3.8 / 3.8 / 3.6 / 3.5).  The first round goes through gams_wave_run on the caller: it
+    // applies the kernel attribute and the first-use stream waits.
+    static const uint32_t max_threads = [] {
+        const char *e = getenv("GAMS_QUEUE_THREADS");          // 1..4; measurement knob
+        const int v = e ? atoi(e) : gams_gpu::kMaxWays;          // default: one queueing thread per way
+        return (uint32_t)std::min(std::max(v, 1), gams_gpu::kMaxWays);
+    }();
+    const uint32_t shares = std::min(max_threads, p->depth);
+    const bool threaded = p->depth >= 3 && shares >= 2 && n >= 4 * p->depth;
     if (!threaded) {
         for (uint32_t i = 0; i < n; ++i) {
             int rc = gams_wave_run(h, p);
@@ -683,30 +698,36 @@ int gams_wave_run_n(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t n) {
         }
         return GAMS_OK;
     }
-    if (!p->launcher) {
-        p->launcher = new Launcher();
-        p->launcher->th = std::thread(wave_launcher_main, p->launcher, h->device);
-    }
-    Launcher *L = p->launcher;
     const uint32_t lead = p->depth;
     const uint32_t rest = n - lead;
-    const uint64_t first = p->run_idx + lead;     // index of the first pass the two threads share
-    {
-        std::lock_guard<std::mutex> lk(L->mu);
-        L->h = h;
-        L->p = p;
-        L->first = first;
-        L->rest = rest;
-        L->go.store(0, std::memory_order_relaxed);
-        L->finished = false;
-        L->armed = true;
+    const uint64_t first = p->run_idx + lead;     // index of the first pass the threads share
+    for (uint32_t t = 1; t < shares; ++t) {
+        Launcher *&L = p->launcher[t - 1];
+        if (!L) {
+            L = new Launcher();
+            L->th = std::thread(wave_launcher_main, L, h->device);
+        }
+        {
+            std::lock_guard<std::mutex> lk(L->mu);
+            L->h = h;
+            L->p = p;
+            L->first = first;
+            L->rest = rest;
+            L->share = t;
+            L->shares = shares;
+            L->go.store(0, std::memory_order_relaxed);
+            L->finished = false;
+            L->armed = true;
+        }
+        L->cv.notify_all();                        // wakes up while the first round is queued
     }
-    L->cv.notify_all();                            // wakes up while the first round is queued
     int rc = GAMS_OK;
     for (uint32_t i = 0; i < lead && rc == GAMS_OK; ++i) rc = gams_wave_run(h, p);
-    L->go.store(rc == GAMS_OK ? 1 : 2, std::memory_order_release);
-    if (rc == GAMS_OK) rc = wave_queue_parity(h, p, first, rest, 0u);
-    {
+    for (uint32_t t = 1; t < shares; ++t)
+        p->launcher[t - 1]->go.store(rc == GAMS_OK ? 1 : 2, std::memory_order_release);
+    if (rc == GAMS_OK) rc = wave_queue_share(h, p, first, rest, 0u, shares);
+    for (uint32_t t = 1; t < shares; ++t) {
+        Launcher *L = p->launcher[t - 1];
         std::unique_lock<std::mutex> lk(L->mu);
         L->cv.wait(lk, [&] { return L->finished; });
         if (rc == GAMS_OK) rc = L->rc;
