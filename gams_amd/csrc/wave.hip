@@ -174,8 +174,8 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
     // fast kernel: 8-bit counts, 32-bit variance math with 24-bit multiplies
     const bool fast_ok = !p->serial && q.size <= 255 && q.step <= 32 && (uint64_t)q.lag * q.size <= 65535 &&
                          (uint64_t)q.lag * q.size * q.size < (1ull << 24) && q.lag >= 2;
-    if (fast_ok && (tw_req == 0 || tw_req == 1024 || tw_req == 3072 || tw_req == 5120)) {
-        static const int cand[3] = {20, 12, 4};
+    if (fast_ok && (tw_req == 0 || tw_req == 1024 || tw_req == 2048 || tw_req == 3072 || tw_req == 5120)) {
+        static const int cand[4] = {20, 12, 8, 4};
         int pick = 0;
         for (int w : cand) {
             const uint64_t tw = 256ull * w;
@@ -550,6 +550,8 @@ static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
         rc = headline ? wave_launch_fast<12, 100, 10, 100>(h, p, a, st)
              : step1  ? wave_launch_fast<12, 100, 1, 100>(h, p, a, st)
                       : wave_launch_fast<12, 0, 0, 0>(h, p, a, st);
+    else if (p->fast_w == 8)
+        rc = headline ? wave_launch_fast<8, 100, 10, 100>(h, p, a, st) : wave_launch_fast<8, 0, 0, 0>(h, p, a, st);
     else if (p->fast_w == 4)
         rc = headline ? wave_launch_fast<4, 100, 10, 100>(h, p, a, st) : wave_launch_fast<4, 0, 0, 0>(h, p, a, st);
     else if (p->k16)

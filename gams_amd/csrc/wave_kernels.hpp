@@ -424,7 +424,7 @@ __global__ void wave_const_table_kernel(int8_t *const_sig, uint32_t size, uint32
 // bit-field offsets in phase 2); 0 = taken from the arguments at run time.
 template <int W, int SIZE, int STEP, int LAG>
 __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
-    static_assert(W % 4 == 0 && ((W / 4) & 1) == 1, "W/4 must be odd (LDS bank stride)");
+    static_assert(W % 4 == 0 && (((W / 4) & 1) == 1 || W == 8), "W/4 odd (LDS bank stride), or W = 8 (64-bit reads)");
     static_assert((SIZE == 0) == (STEP == 0) && (SIZE == 0) == (LAG == 0), "bake all three or none");
     if (a.stamps != nullptr && threadIdx.x == 0)
         a.stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();  // workgroup entry

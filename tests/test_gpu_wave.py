@@ -311,3 +311,28 @@ def test_run_n_equals_repeated_run(eng, s288c, depth, n):
     assert np.array_equal(plan.peaks(), ref)
     plan.close()
     ss.close()
+
+
+@pytest.mark.parametrize("prm", [(100, 10, 100, 3.0), (100, 1, 100, 3.0), (50, 7, 33, 2.0), (255, 8, 60, 1.0)])
+@pytest.mark.parametrize("tile", [1024, 2048, 3072, 5120])
+def test_every_fast_tile_size_matches_the_oracle(eng, s288c, prm, tile):
+    """W = 4 / 8 / 12 / 20 windows per thread (tile 1024 / 2048 / 3072 / 5120), baked and run-time parameters."""
+    seqs = [bytes(s288c["I"]), synth(33333, 3).tobytes(), bytes(s288c["Mito"][:20000])]
+    ss = engine.SeqSet(eng, seqs)
+    try:
+        plan = engine.WavePlan(eng, ss, *prm, 1.0, flags=_lib.WAVE_PEAKS | _lib.WAVE_DENSE, tile_windows=tile)
+    except _lib.GamsError as e:
+        assert e.code == _lib.EUNSUPPORTED
+        ss.close()
+        return
+    plan.run()
+    pk = plan.peaks()
+    for c, s in enumerate(seqs):
+        ocnt, _, osig = ora.wave_windows(s, *prm, 1.0)
+        cnt, sig = plan.dense(c)
+        assert np.array_equal(cnt, ocnt) and np.array_equal(sig.astype(np.int32), osig), (prm, tile, c)
+        mine = pk[pk["ctg"] == c]
+        idx = np.flatnonzero(osig)
+        assert np.array_equal(mine["window"], idx) and np.array_equal(mine["signal"], osig[idx])
+    plan.close()
+    ss.close()

@@ -4,7 +4,7 @@ from gams_amd import _lib, engine, synth
 eng = engine.Engine(0)
 ctgs = synth.genome_ctgs(synth.S288C_LENGTHS, 500000)
 ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])
-for tw in (1024, 3072, 5120):
+for tw in (1024, 2048, 3072):
     plan = engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS, tile_windows=tw)
     nw = plan.total_windows
     for depth in (1, 4):
