@@ -1,6 +1,8 @@
 """Randomised parameter sweep of the wave path on the GPU against the oracle: sizes, steps
 (smaller than, equal to and larger than the size), lags and thresholds drawn at random, ragged
 ctg lengths, every kernel variant (baked / run-time fast kernels, general kernel, serial path)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -34,7 +36,11 @@ def random_seq(rng, n):
     return s
 
 
-@pytest.mark.parametrize("seed", range(64))
+# GAMS_FUZZ_SEEDS=first:count widens the sweep (profiles/r01_fuzz_log.txt: 22,000 seeds)
+_FIRST, _COUNT = (int(x) for x in os.environ.get("GAMS_FUZZ_SEEDS", "0:64").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + _COUNT))
 def test_random_parameters(eng, seed):
     rng = np.random.default_rng(1000 + seed)
     size = int(rng.choice([1, 7, 10, 50, 64, 100, 100, 100, 128, 200, 255, 256, 300, 1000]))
