@@ -332,7 +332,10 @@ extern "C" int gams_gpu_sw(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, int32_t 
     if (!h || !s || !n_rows || (nf && (!feat_start || !feat_end)))
         return gams_fail(h, GAMS_EINVAL, "gpu_sw: null argument");
     if (i >= s->n_ctg) return gams_fail(h, GAMS_EINVAL, "gpu_sw: ctg index out of range");
-    if (size <= 0 || max < 0 || resize < 0) return gams_fail(h, GAMS_EINVAL, "gpu_sw: size > 0, max >= 0, resize >= 0");
+    // size or resize 1: half_resize = 0 makes center_resize slice [mid+1, mid-1] (window.rs:113-123),
+    // an empty span whose min()/max() the reference then asks for -- no defined answer to mirror
+    if (size < 2 || max < 0 || resize < 2)
+        return gams_fail(h, GAMS_EINVAL, "gpu_sw: size >= 2, max >= 0, resize >= 2 (center_resize of 1 bp is an empty span)");
     if (s->len[i] == 0 || s->len[i] > 0x7fffffffu) return gams_fail(h, GAMS_EINVAL, "gpu_sw: ctg length out of range");
     GAMS_HIP(h, hipSetDevice(h->device));
     *n_rows = 0;

@@ -373,3 +373,14 @@ def test_command_tsv_of_loader_records(eng, s288c):
     for row, (k, js) in zip(ft[1:], recs):
         rec = json.loads(js)
         assert row.split("\t") == [rec["id"], rec["range"], str(rec["length"]), rec["tag"]]
+
+
+def test_sw_rejects_one_bp_windows(eng, s288c):
+    """size or resize 1: center_resize slices [mid+1, mid-1] (window.rs:113-123), an empty span the reference
+    then takes min()/max() of; the C ABI reports it instead."""
+    c = helpers.gen_ctgs("I", s288c["I"], piece=100000)[0]
+    feats = [("feature:x:1", c["chr_start"] + 500, c["chr_start"] + 500)]
+    for size, resize in ((1, 500), (100, 1), (0, 500)):
+        with pytest.raises(Exception) as ei:
+            host.sw(eng, c, feats, size, 20, resize)
+        assert "size >= 2" in str(ei.value)
