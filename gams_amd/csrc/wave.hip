@@ -50,6 +50,7 @@ struct gams_wave_plan {
     gams_wave_params_t prm{};
     uint32_t flags = 0;
     bool serial = false;          // influence != 1
+    bool direct = false;          // halo beyond a tile: one lane per window, no tiling (wave_direct_*_kernel)
     bool wide = false, k16 = false;
     int fast_w = 0;               // W of wave_fast_kernel (0: generic wave_tile_kernel)
     uint32_t tw = 0;              // windows per tile
@@ -171,6 +172,7 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
     const uint64_t halo_bytes = (uint64_t)(q.lag + 1) * q.step + (uint64_t)q.size + 32;
     p->fast_w = 0;
     p->attr_set = false;
+    p->direct = false;
     // fast kernel: 8-bit counts, 32-bit variance math with 24-bit multiplies
     const bool fast_ok = !p->serial && q.size <= 255 && q.step <= 32 && (uint64_t)q.lag * q.size <= 65535 &&
                          (uint64_t)q.lag * q.size * q.size < (1ull << 24) && q.lag >= 2;
@@ -220,9 +222,19 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
     tw = std::min(tw, kMaxTw) & ~255u;
     if (tw < 256) tw = 256;
     while (tw > 256 && halo_bytes + (uint64_t)tw * q.step > kMaxTileBytes) tw -= 256;
-    if (halo_bytes + (uint64_t)tw * q.step > kMaxTileBytes)
-        return gams_fail(h, GAMS_EUNSUPPORTED,
-                         "wave: (lag+1)*step + size + 256*step exceeds the 64 KB tile of the fused kernel");
+    auto go_direct = [&] {
+        // (lag+1)*step + size + 256*step beyond the 64-KB tile, or prefix arrays beyond the LDS:
+        // untiled kernels; the tile table only serves the peak compaction
+        p->direct = true;
+        p->tw = 1024;
+        p->max_win = 0;
+        p->max_chunks = 0;
+        p->k16 = p->wide = false;
+        p->lds_bytes = 0;
+        wave_fill_tiles(p);
+        return GAMS_OK;
+    };
+    if (halo_bytes + (uint64_t)tw * q.step > kMaxTileBytes) return go_direct();
     p->tw = tw;
     p->max_win = tw + q.lag + 1;
     p->max_chunks = (uint32_t)((halo_bytes + (uint64_t)tw * q.step + 15) / 16) + 1;
@@ -233,8 +245,7 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
     p->wide = !(ns <= 65535 && q2max < (1ull << 32));
     p->lds_bytes = wave_lds_bytes(p->max_chunks, p->max_win, p->wide, p->k16);
     p->attr_set = false;
-    if (p->lds_bytes > 160 * 1024)
-        return gams_fail(h, GAMS_EUNSUPPORTED, "wave: tile does not fit the 160 KB LDS");
+    if (p->lds_bytes > 160 * 1024) return go_direct();
     wave_fill_tiles(p);
     return GAMS_OK;
 }
@@ -297,7 +308,7 @@ int wave_upload_geometry(gams_gpu_t *h, gams_wave_plan_t *p) {
 // per-way buffers that do not depend on the tiling: counter ring, dense rows, filtered[]
 int wave_alloc_ways(gams_gpu_t *h, gams_wave_plan_t *p) {
     const uint64_t base = std::max<uint64_t>(p->total_windows, 1);
-    const bool need_dense = (p->flags & GAMS_WAVE_DENSE) || p->serial;
+    const bool need_dense = (p->flags & GAMS_WAVE_DENSE) || p->serial || p->direct;
     for (uint32_t k = 0; k < p->depth; ++k) {
         gams_wave_plan::Way &w = p->way[k];
         if (!w.d_counters) {
@@ -541,10 +552,25 @@ static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
     a.tile_cnt = w.d_tile_cnt;
     a.dense_cnt = w.d_dense_cnt;
     a.dense_sig = w.d_dense_sig;
-    int rc;
+    if (p->direct) {
+        const uint64_t total = p->total_windows;
+        const unsigned blocks = (unsigned)((total + 255) / 256);
+        hipLaunchKernelGGL(wave_direct_count_kernel, dim3(blocks), dim3(256), 0, st, p->set->d_seq, p->d_ctgs,
+                           p->set->n_ctg, total, (uint32_t)q.size, (uint32_t)q.step, w.d_dense_cnt);
+        GAMS_HIP(h, hipGetLastError());
+        if (!p->serial) {
+            hipLaunchKernelGGL(wave_direct_signal_kernel, dim3(blocks), dim3(256), 0, st, p->d_ctgs, p->set->n_ctg,
+                               total, w.d_dense_cnt, w.d_dense_sig, q.lag, q.threshold, (float)q.size,
+                               q.lag < 2 ? 1u : 0u);
+            GAMS_HIP(h, hipGetLastError());
+        }
+    }
+    int rc = GAMS_OK;
     const bool headline = q.size == 100 && q.step == 10 && q.lag == 100;   // every BASELINE step-10 config
     const bool step1 = q.size == 100 && q.step == 1 && q.lag == 100;       // BASELINE configs[3] (GRCh38, step 1)
-    if (p->fast_w == 20)
+    if (p->direct)
+        ;   // counted and decided above
+    else if (p->fast_w == 20)
         rc = step1 ? wave_launch_fast<20, 100, 1, 100>(h, p, a, st) : wave_launch_fast<20, 0, 0, 0>(h, p, a, st);
     else if (p->fast_w == 12)
         rc = headline ? wave_launch_fast<12, 100, 10, 100>(h, p, a, st)
@@ -559,6 +585,11 @@ static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
     else
         rc = p->wide ? wave_launch<uint8_t, true>(h, p, a, st) : wave_launch<uint8_t, false>(h, p, a, st);
     if (rc != GAMS_OK) return rc;
+    if (p->direct && !p->serial && (p->flags & GAMS_WAVE_PEAKS)) {
+        hipLaunchKernelGGL(wave_compact_kernel, dim3((unsigned)p->tiles.size()), dim3(256), 0, st, p->d_ctgs,
+                           p->d_tiles, p->tw, w.d_dense_cnt, w.d_dense_sig, w.d_peaks, p->tile_cap, w.d_tile_cnt);
+        GAMS_HIP(h, hipGetLastError());
+    }
     if (p->serial) {
         const uint32_t n = p->set->n_ctg;
         hipLaunchKernelGGL(wave_serial_kernel, dim3((n + 63) / 64), dim3(64), 0, st, p->d_ctgs, n, w.d_dense_cnt,

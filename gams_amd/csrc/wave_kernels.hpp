@@ -807,6 +807,59 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
     wave_stamp(a, 6);
 }
 
+// ---- parameters whose halo does not fit a tile (large step or lag): no tiling ---------------
+// (lag+1)*step + size + 256*step > 64 KB, or the LDS prefix arrays > 160 KB: one lane per window
+// counts its own bases straight from HBM (windows barely overlap at such steps), a second kernel
+// evaluates every window in the reference's exact f32 order over the dense counts (no guard band
+// to speak of: this IS the exact path), wave_compact_kernel collects the peaks.  Few windows per
+// base, so the simple form costs little; bit-exact like everything else.
+__device__ __forceinline__ uint32_t wave_ctg_of(const WaveCtgDev *ctgs, uint32_t n_ctg, uint64_t g) {
+    uint32_t lo = 0, hi = n_ctg;               // last ctg whose win_base <= g
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (ctgs[mid].win_base <= g)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void wave_direct_count_kernel(const uint8_t *seq, const WaveCtgDev *ctgs,
+                                                                 uint32_t n_ctg, uint64_t total, uint32_t size,
+                                                                 uint32_t step, uint32_t *dense_cnt) {
+    const uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (g >= total) return;
+    const WaveCtgDev cg = ctgs[wave_ctg_of(ctgs, n_ctg, g)];
+    const uint64_t b0 = cg.seq_off + (g - cg.win_base) * (uint64_t)step, b1 = b0 + size;   // window.rs:78-94
+    uint32_t cnt = 0;
+    // whole aligned dwords around [b0, b1): bytes outside are masked (the buffer is 256-B aligned
+    // in front and has tail slack behind)
+    for (uint64_t a = b0 & ~(uint64_t)3; a < b1; a += 4) {
+        uint32_t f = gc_flags(*reinterpret_cast<const uint32_t *>(seq + a));
+        if (a < b0) f &= ~0u << (8u * (uint32_t)(b0 - a));
+        if (a + 4 > b1) f &= ~0u >> (8u * (uint32_t)(a + 4 - b1));
+        cnt += (uint32_t)__popc(f);
+    }
+    dense_cnt[g] = cnt;
+}
+
+__global__ __launch_bounds__(256) void wave_direct_signal_kernel(const WaveCtgDev *ctgs, uint32_t n_ctg,
+                                                                  uint64_t total, const uint32_t *dense_cnt,
+                                                                  int8_t *dense_sig, uint32_t lag, float thr,
+                                                                  float fsize, uint32_t no_signal) {
+    const uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (g >= total) return;
+    const WaveCtgDev cg = ctgs[wave_ctg_of(ctgs, n_ctg, g)];
+    const uint32_t i = (uint32_t)(g - cg.win_base);
+    int sg = 0;
+    if (!no_signal && i >= lag) {
+        const uint32_t tj = i == lag ? 0u : i - 1u - lag;              // stat.rs:30-31 / :51-52
+        sg = exact_signal<uint32_t>(dense_cnt + cg.win_base, tj, i, lag, fsize, thr);
+    }
+    dense_sig[g] = (int8_t)sg;
+}
+
 // ---- influence != 1: the filtered[] recurrence is serial per ctg -------------
 // One lane per ctg, the reference's loop verbatim (stat.rs:16-56) over the dense
 // gc counts a counts-only pass of wave_tile_kernel left in HBM.  `ring` holds

@@ -37,7 +37,7 @@ extern "C" {
 #define GAMS_ENOMEM 3       /* host or device allocation failed */
 #define GAMS_EHIP 4         /* a HIP call failed (message has the HIP error) */
 #define GAMS_ESHORT 5       /* a ctg has fewer windows than lag: the reference panics (stat.rs:30) */
-#define GAMS_EUNSUPPORTED 6 /* parameter combination outside what the kernels implement */
+#define GAMS_EUNSUPPORTED 6 /* outside what the kernels implement (sizes / lags beyond 65535, counts beyond 2^31) */
 #define GAMS_ESTATE 7       /* call order violated (e.g. results read before run) */
 
 typedef struct gams_gpu gams_gpu_t;

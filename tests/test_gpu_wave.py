@@ -336,3 +336,36 @@ def test_every_fast_tile_size_matches_the_oracle(eng, s288c, prm, tile):
         assert np.array_equal(mine["window"], idx) and np.array_equal(mine["signal"], osig[idx])
     plan.close()
     ss.close()
+
+
+@pytest.mark.parametrize("size,step,lag,thr,infl", [
+    (1000, 500, 100, 3.0, 1.0),      # coarse scan: tile bytes beyond 64 KB
+    (300, 150, 200, 2.0, 1.0),
+    (100, 700, 50, 2.5, 1.0),        # step > size: gaps between windows
+    (50, 3, 30000, 3.0, 1.0),        # prefix arrays beyond the LDS
+    (1000, 500, 100, 2.0, 0.5),      # + the serial recurrence
+    (65535, 300, 2, 1.0, 1.0),       # the largest window
+])
+def test_untiled_path_for_halos_beyond_a_tile(eng, size, step, lag, thr, infl):
+    """(lag+1)*step + size + 256*step > 64 KB or LDS overflow: wave_direct_*_kernel; same answers."""
+    need = size + (lag + 40) * step
+    seqs = [synth(need + 7777, 21).tobytes(), synth(need + 123, 22, gc=0.55).tobytes()]
+    ss = engine.SeqSet(eng, seqs)
+    plan = engine.WavePlan(eng, ss, size, step, lag, thr, infl, flags=_lib.WAVE_PEAKS | _lib.WAVE_DENSE)
+    plan.run()
+    pk = plan.peaks()
+    for c, s in enumerate(seqs):
+        ocnt, _, osig = ora.wave_windows(s, size, step, lag, thr, infl)
+        cnt, sig = plan.dense(c)
+        assert np.array_equal(cnt, ocnt) and np.array_equal(sig.astype(np.int32), osig), (size, step, lag, c)
+        mine = pk[pk["ctg"] == c]
+        idx = np.flatnonzero(osig)
+        assert np.array_equal(mine["window"], idx) and np.array_equal(mine["signal"], osig[idx])
+        assert np.array_equal(mine["gc_count"], ocnt[idx])
+    # peaks-only plan (no DENSE requested) goes the same way
+    p2 = engine.WavePlan(eng, ss, size, step, lag, thr, infl, flags=_lib.WAVE_PEAKS)
+    p2.run()
+    assert np.array_equal(p2.peaks(), pk)
+    p2.close()
+    plan.close()
+    ss.close()
