@@ -20,7 +20,8 @@
 //       mask), k[w] = P(w*step+size) - P(w*step), prefix arrays Q1 = sum k, Q2 = sum k^2,
 //       same decision + guard band, scalar exact path.
 // Signals are bit-identical to thresholding_algo in both (the guard band only decides
-// which windows take the exact path).
+// which windows take the exact path).  Parameters whose halo does not fit a tile at all (large
+// steps, very large lags) run untiled: wave_direct_count_kernel + wave_direct_signal_kernel.
 //
 // influence != 1 makes filtered[] (stat.rs:42) a true serial recurrence: those
 // runs use wave_serial_kernel (one lane per ctg, exact f32 order) on the counts of a
