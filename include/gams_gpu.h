@@ -55,8 +55,9 @@ int gams_gpu_device_info(gams_gpu_t *h, char *arch, size_t arch_len,
                          int32_t *compute_units, uint64_t *hbm_bytes);
 /* block until everything queued on the handle's streams has finished */
 int gams_gpu_sync(gams_gpu_t *h);
-/* HIP-event stopwatch on the handle's compute stream (the stream every kernel
- * of this library is launched on).  stop() synchronises and returns ms. */
+/* HIP-event stopwatch on the handle's compute stream (the stream the kernels of this library
+ * are launched on; plans of depth > 1 also use auxiliary streams, which stop() queues the
+ * compute stream behind before it records the closing event).  stop() synchronises and returns ms. */
 int gams_gpu_timer_start(gams_gpu_t *h);
 int gams_gpu_timer_stop(gams_gpu_t *h, float *ms);
 /* Device time (HIP events around the kernel, excluding the host<->device copies) of the last
