@@ -40,6 +40,7 @@ PROTOTYPES = {
     "gams_gpu_destroy": (None, [_VP]),
     "gams_gpu_last_error": (C.c_char_p, [_VP]),
     "gams_gpu_device_info": (C.c_int, [_VP, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
+    "gams_gpu_release_cached": (C.c_int, [_VP, _VP]),
     "gams_gpu_sync": (C.c_int, [_VP]),
     "gams_gpu_timer_start": (C.c_int, [_VP]),
     "gams_gpu_timer_stop": (C.c_int, [_VP, C.POINTER(C.c_float)]),

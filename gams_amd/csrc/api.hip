@@ -102,6 +102,24 @@ int gams_gpu_sync(gams_gpu_t *h) {
     return GAMS_OK;
 }
 
+int gams_gpu_release_cached(gams_gpu_t *h, uint64_t *cached_bytes) {
+    if (!h) return GAMS_EINVAL;
+    GAMS_HIP(h, hipSetDevice(h->device));
+    uint64_t held = 0;
+    for (auto &b : h->dev_pool) {
+        held += b.bytes;
+        (void)hipFree(b.p);
+    }
+    for (auto &b : h->pin_pool) {
+        held += b.bytes;
+        (void)hipHostFree(b.p);
+    }
+    h->dev_pool.clear();
+    h->pin_pool.clear();
+    if (cached_bytes) *cached_bytes = held;
+    return GAMS_OK;
+}
+
 int gams_gpu_timer_start(gams_gpu_t *h) {
     if (!h) return GAMS_EINVAL;
     GAMS_HIP(h, hipSetDevice(h->device));

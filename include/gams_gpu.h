@@ -55,6 +55,10 @@ int gams_gpu_device_info(gams_gpu_t *h, char *arch, size_t arch_len,
                          int32_t *compute_units, uint64_t *hbm_bytes);
 /* block until everything queued on the handle's streams has finished */
 int gams_gpu_sync(gams_gpu_t *h);
+/* Freed HBM and pinned-host blocks stay cached on the handle for the next batch (at most 16
+ * blocks, a quarter of the HBM, 1 GiB pinned); this returns them to the driver now.
+ * cached_bytes (may be NULL) receives what was held. */
+int gams_gpu_release_cached(gams_gpu_t *h, uint64_t *cached_bytes);
 /* HIP-event stopwatch on the handle's compute stream (the stream the kernels of this library
  * are launched on; plans of depth > 1 also use auxiliary streams, which stop() queues the
  * compute stream behind before it records the closing event).  stop() synchronises and returns ms. */

@@ -369,3 +369,23 @@ def test_untiled_path_for_halos_beyond_a_tile(eng, size, step, lag, thr, infl):
     p2.close()
     plan.close()
     ss.close()
+
+
+def test_block_pool_is_reused_and_can_be_released(eng, s288c):
+    """freed HBM / pinned blocks stay on the handle for the next batch; gams_gpu_release_cached drops them"""
+    import ctypes as C
+
+    held = C.c_uint64()
+    eng.check(eng.lib.gams_gpu_release_cached(eng.h, C.byref(held)))
+    for _ in range(3):
+        ss = engine.SeqSet(eng, [bytes(s288c["I"])])
+        plan = engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS)
+        plan.run()
+        n = plan.peaks().size
+        plan.close()
+        ss.close()
+    eng.check(eng.lib.gams_gpu_release_cached(eng.h, C.byref(held)))
+    assert n > 0 and held.value >= len(s288c["I"])          # at least the sequence block was cached
+    eng.check(eng.lib.gams_gpu_release_cached(eng.h, C.byref(held)))
+    assert held.value == 0
+    check_dense(eng, s288c["Mito"][:30000], 100, 10, 100, 3.0)   # and the handle keeps working
