@@ -58,6 +58,8 @@ def load():
     L.gams_host_encode_gz.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.gams_host_loader_records.restype = C.c_void_p
     L.gams_host_loader_records.argtypes = [C.c_void_p, C.c_uint32, sp, sp, ip, ip, C.c_char_p, C.c_char_p]
+    L.gams_host_header.restype = C.c_void_p
+    L.gams_host_header.argtypes = [C.c_int]
     L.gams_host_tsv_ctgs.restype = C.c_void_p
     L.gams_host_tsv_ctgs.argtypes = [C.c_uint32, sp, sp, ip, ip]
     L.gams_host_loader_tsv.restype = C.c_void_p
@@ -198,6 +200,11 @@ def loader_records(eng, ctgs, lines, tag=None):
     out = _take(load().gams_host_loader_records(eng.h, n, ids, chrs, st.ctypes.data, en.ctypes.data,
                                                 "\n".join(lines).encode(), tag.encode() if tag is not None else None))
     return [tuple(r.split("\t", 1)) for r in out.splitlines()]
+
+
+def header(command):
+    """the header line `gams wave` / `gams sw` print before the rows"""
+    return _take(load().gams_host_header(0 if command == "wave" else 1))
 
 
 def tsv_ctgs(ctgs):

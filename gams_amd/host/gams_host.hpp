@@ -146,6 +146,10 @@ std::vector<Peak> peak_records(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq
 struct Record {
     std::string key, json;
 };
+// header lines the commands print in front of the per-ctg rows (wave.rs:263-266, sw.rs:204-216)
+inline const char *wave_header() { return "#range\tgc_content\tsignal\n"; }
+inline const char *sw_header() { return "id\trange\ttype\tdistance\tgc_content\tgc_mean\tgc_stddev\tgc_cv\trg_count\n"; }
+
 // src/cmd_gams/tsv.rs:31-71: `gams tsv -s "ctg:*"` = a header of the struct's field names
 // (data.rs:5-14, serde order) and one tab-separated row per record; ctgs in the order given.
 std::string tsv_ctgs(const std::vector<Ctg> &ctgs);

@@ -308,6 +308,9 @@ char *gams_host_tsv_ctgs(uint32_t n, const char *const *ids, const char *const *
     return guarded([&] { return gams::tsv_ctgs(make_ctgs(n, ids, chrs, starts, ends)); });
 }
 
+// header lines of `gams wave` (which == 0) and `gams sw` (which == 1)
+char *gams_host_header(int which) { return dup(which == 0 ? gams::wave_header() : gams::sw_header()); }
+
 // formatting helpers exposed for CPU-only tests
 char *gams_host_fmt_f32(float v) { return dup(gams::fmt_f32(v)); }
 char *gams_host_range_roundtrip(const char *s) {

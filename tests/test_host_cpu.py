@@ -69,3 +69,13 @@ def test_command_tsv_ctgs_reproduces_the_fixture():
     assert "chr_strand\tlength" in out[0] and any("ctg:I:2" in r for r in out)
     assert out[0] == lines[0]
     assert out[1:] == lines[1:]
+
+
+def test_command_headers():
+    """wave.rs:263-266 and sw.rs:204-216; tests/S288c/I.peaks.tsv starts with the wave header"""
+    import helpers
+
+    assert host.header("wave") == "#range\tgc_content\tsignal\n"
+    assert host.header("wave").rstrip("\n") == helpers.read_lines("I.peaks.tsv")[0]
+    assert host.header("sw").rstrip("\n").split("\t") == ["id", "range", "type", "distance", "gc_content", "gc_mean",
+                                                           "gc_stddev", "gc_cv", "rg_count"]
