@@ -36,7 +36,7 @@ def random_seq(rng, n):
     return s
 
 
-# GAMS_FUZZ_SEEDS=first:count widens the sweep (profiles/r01_fuzz_log.txt: 22,000 seeds)
+# GAMS_FUZZ_SEEDS=first:count widens the sweep (profiles/r01_fuzz_log.txt: 122,000 seeds)
 _FIRST, _COUNT = (int(x) for x in os.environ.get("GAMS_FUZZ_SEEDS", "0:64").split(":"))
 
 
