@@ -53,3 +53,27 @@ def test_no_gpu_means_loud_failure():
 
     with pytest.raises(_lib.GamsError):
         engine.Engine(0)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/gams_gpu.h must compile as C99 (a Rust/C/Go host binds it as a C ABI) and link against the library."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include "gams_gpu.h"\n'
+        "int main(void) {\n"
+        "    gams_wave_params_t p = {100, 10, 100u, 3.0f, 1.0f};\n"
+        "    gams_peak_t pk = {0u, 0u, 0u, 0};\n"
+        "    gams_gpu_t *h = 0;\n"
+        "    (void)p; (void)pk;\n"
+        "    /* no device here: the call must fail cleanly, not crash */\n"
+        "    return gams_window_count(230218, 100, 10) == 23012 && gams_gpu_last_error(h) != 0 ? 0 : 1;\n"
+        "}\n")
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           str(src), "-o", str(exe), "-L", os.path.join(root, "gams_amd"), "-lgams_gpu",
+                           "-Wl,-rpath," + os.path.join(root, "gams_amd")])
+    assert subprocess.call([str(exe)]) == 0
