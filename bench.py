@@ -91,7 +91,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5000,
+                    help="untimed passes before the timed region (the clocks take a few ms of load to settle)")
     ap.add_argument("--workload", default="S288c", choices=sorted(WORKLOADS))
     ap.add_argument("--scale", type=float, default=1.0, help="shrink/grow chromosome lengths (testing)")
     ap.add_argument("--tile", type=int, default=0, help="windows per tile (0 = library default)")
