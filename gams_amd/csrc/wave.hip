@@ -196,9 +196,12 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
             // kernel (measured 452 vs 503 us on 3.8e8 windows), otherwise only on request.
             const uint64_t tiles = p->total_windows / tw;
             const bool step1 = q.size == 100 && q.step == 1 && q.lag == 100;   // baked W = 20 fits 64 VGPRs
+            // W = 8 sits between: with passes in flight 2.84 us per 12-Mb pass against 3.02 at W = 4
+            // (one pass alone: 8.2 against 7.9 us, so only then).
             const uint64_t enough12 = p->depth >= 2 ? 512 : 640;
             if (pick == 0 && w == 20 && step1 && tiles >= 1024) pick = w;
             if (pick == 0 && w == 12 && tiles >= enough12) pick = w;
+            if (pick == 0 && w == 8 && p->depth >= 2 && tiles >= 512) pick = w;
             if (pick == 0 && w == 4) pick = w;
         }
         if (pick) {
