@@ -187,21 +187,23 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
                 if (tw_req == tw) pick = w;
                 continue;
             }
-            // default: W = 12 once that gives enough tiles, else W = 4 (more, shorter workgroups: a
-            // small genome is launch-latency bound).  Measured per pass, W = 4 / W = 12, one pass at
-            // a time and four in flight: 1.2 M windows (399 tiles of W = 12) 8.1 / 9.3 us and
-            // 3.3 / 3.1 us; 2.4 M (791) 11.5 / 11.4 and 6.4 / 4.6; 3.6 M (1187) 15.0 / 14.5 and
-            // 9.3 / 6.7 -- with passes in flight the W = 12 kernel's lower instruction count per
-            // window decides (5.3e11 against 3.8e11 windows/s).  W = 20 for the baked step-1
-            // kernel (measured 452 vs 503 us on 3.8e8 windows), otherwise only on request.
+            // Default W by the number of tiles it would give (a small genome is launch-latency
+            // bound and wants many short workgroups; a saturated chip wants the lower instruction
+            // count per window of the bigger tiles).  Measured us per pass, W = 4 / 8 / 12, one pass
+            // at a time | four in flight:
+            //   1.2 M windows   7.9 /  8.2 /  9.3  |  3.02 / 2.84 / 3.07
+            //   1.8 M           9.1 /  9.2 / 10.3  |  4.34 / 3.45 / 3.55
+            //   2.4 M          11.3 / 10.4 / 11.0  |  5.76 / 4.35 / 4.07
+            //   3.6 M          15.0 / 14.2 / 14.2  |  8.42 / 6.44 / 5.91
+            //   38 M (384 Mb)   107 /   82 /   77
+            // W = 20 for the baked step-1 kernel (measured 452 vs 503 us on 3.8e8 windows), otherwise
+            // only on request.
             const uint64_t tiles = p->total_windows / tw;
             const bool step1 = q.size == 100 && q.step == 1 && q.lag == 100;   // baked W = 20 fits 64 VGPRs
-            // W = 8 sits between: with passes in flight 2.84 us per 12-Mb pass against 3.02 at W = 4
-            // (one pass alone: 8.2 against 7.9 us, so only then).
-            const uint64_t enough12 = p->depth >= 2 ? 512 : 640;
+            const bool flight = p->depth >= 2;
             if (pick == 0 && w == 20 && step1 && tiles >= 1024) pick = w;
-            if (pick == 0 && w == 12 && tiles >= enough12) pick = w;
-            if (pick == 0 && w == 8 && p->depth >= 2 && tiles >= 512) pick = w;
+            if (pick == 0 && w == 12 && tiles >= (flight ? 768u : 1536u)) pick = w;
+            if (pick == 0 && w == 8 && tiles >= (flight ? 512u : 1024u)) pick = w;
             if (pick == 0 && w == 4) pick = w;
         }
         if (pick) {
