@@ -37,3 +37,17 @@ for _ in range(10):
     best = min(best, time.perf_counter() - t0)
 print(f"S288c one batch: {best * 1e3:.2f} ms for {sb} bases, {sw_} windows, {out.count(chr(10))} rows -> "
       f"{sw_ / best / 1e9:.2f} G windows/s, {sb / best / 1e9:.2f} GB/s of sequence")
+
+# the reference's own published case: A. thaliana, wave size 100 step 10 lag 100, 3.169 s wall with -p 8
+# (results/Atha.md:207-215, incl. Redis GET + gunzip); here host buffers in -> TSV rows out
+atha = [dict(id=c["id"], chr_id=c["chr_id"], chr_start=c["chr_start"], chr_end=c["chr_end"], seq=c["seq"])
+        for c in synth.genome_ctgs(synth.ATHA_LENGTHS, 500000)]
+ab = sum(len(c["seq"]) for c in atha)
+aw = sum((len(c["seq"]) - 100) // 10 + 1 for c in atha)
+best = 1e9
+for _ in range(4):
+    t0 = time.perf_counter()
+    out = host.wave(eng, atha)
+    best = min(best, time.perf_counter() - t0)
+print(f"Atha-shaped one batch: {best * 1e3:.2f} ms for {ab} bases, {aw} windows, {out.count(chr(10))} rows -> "
+      f"{aw / best / 1e9:.2f} G windows/s, {ab / best / 1e9:.2f} GB/s of sequence")
