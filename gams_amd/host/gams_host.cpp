@@ -477,36 +477,61 @@ std::string sw_proc_ctg(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq, const
     check(h, gams_gpu_sw(h, sg.s, 0, ctg.chr_start, fs.data(), fe.data(), nf, a.size, a.max, a.resize,
                          rows.data(), nrows, &nrows));
     static const char *TYPES[3] = {"M", "L", "R"};
-    out.reserve(nrows * 80);
-    uint32_t cur = UINT32_MAX, sn = 0;
-    for (uint64_t r = 0; r < nrows; ++r) {                              // sw.rs:152-190
-        const gams_sw_row_t &w = rows[r];
-        if (w.feature != cur) {
-            cur = w.feature;
-            sn = 1;                                                     // sw.rs:148
+    // text of rows [r0, r1), r0 on a feature boundary (the serial number restarts per feature)
+    auto format = [&](uint64_t r0, uint64_t r1, std::string &o) {
+        o.reserve((r1 - r0) * 80);
+        uint32_t cur = UINT32_MAX, sn = 0;
+        for (uint64_t r = r0; r < r1; ++r) {                            // sw.rs:152-190
+            const gams_sw_row_t &w = rows[r];
+            if (w.feature != cur) {
+                cur = w.feature;
+                sn = 1;                                                 // sw.rs:148
+            }
+            o += "sw:";                                                 // sw.rs:153
+            o += features[w.feature].id;
+            o += ':';
+            o += std::to_string(sn++);
+            o += '\t';
+            o += ctg.chr_id;                                            // sw.rs:157 Range::from(chr, min, max)
+            o += ':';
+            o += runlist(w.start, w.end);
+            o += '\t';
+            o += TYPES[w.type];
+            o += '\t';
+            o += std::to_string(w.distance);
+            o += '\t';
+            o += fmt_f32(w.gc_content);                                 // data.rs:61-67
+            o += '\t';
+            o += fmt_f32(w.gc_mean);
+            o += '\t';
+            o += fmt_f32(w.gc_stddev);
+            o += '\t';
+            o += fmt_f32(w.gc_cv);
+            o += "\t\n";                                                // empty rg_count (data.rs:71-80)
         }
-        out += "sw:";                                                   // sw.rs:153
-        out += features[w.feature].id;
-        out += ':';
-        out += std::to_string(sn++);
-        out += '\t';
-        out += ctg.chr_id;                                              // sw.rs:157 Range::from(chr, min, max)
-        out += ':';
-        out += runlist(w.start, w.end);
-        out += '\t';
-        out += TYPES[w.type];
-        out += '\t';
-        out += std::to_string(w.distance);
-        out += '\t';
-        out += fmt_f32(w.gc_content);                                   // data.rs:61-67
-        out += '\t';
-        out += fmt_f32(w.gc_mean);
-        out += '\t';
-        out += fmt_f32(w.gc_stddev);
-        out += '\t';
-        out += fmt_f32(w.gc_cv);
-        out += "\t\n";                                                  // empty rg_count (data.rs:71-80)
+    };
+    // a few host threads, each a run of whole features
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({8, std::thread::hardware_concurrency(), nrows / 20000}));
+    if (T <= 1) {
+        format(0, nrows, out);
+        return out;
     }
+    std::vector<uint64_t> cut(T + 1, nrows);
+    cut[0] = 0;
+    for (unsigned t = 1; t < T; ++t) {
+        uint64_t b = std::max(cut[t - 1], nrows * t / T);
+        while (b < nrows && b > 0 && rows[b].feature == rows[b - 1].feature) ++b;
+        cut[t] = b;
+    }
+    std::vector<std::string> part(T);
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < T; ++t) pool.emplace_back([&, t] { format(cut[t], cut[t + 1], part[t]); });
+    format(cut[0], cut[1], part[0]);
+    for (auto &th : pool) th.join();
+    size_t total = 0;
+    for (auto &x : part) total += x.size();
+    out.reserve(total);
+    for (auto &x : part) out += x;
     return out;
 }
 
