@@ -45,10 +45,18 @@ def test_config1_s288c_full_genome(eng):
     ctgs = synth.genome_ctgs(synth.S288C_LENGTHS, 500000)
     ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])
     exp = oracle_peaks(ctgs, 100, 10, 100, 3.0)
-    for tile in (0, 1024, 3072, 5120, 2048):        # 2048: the general (prefix-array) kernel
+    for tile in (0, 1024, 2048, 3072, 5120, 1536):  # W = 4 / 8 / 12 / 20; 1536: the general (prefix-array) kernel
         pk, n = gpu_peaks(eng, ss, 100, 10, 100, 3.0, tile)
         assert n == 1215506
         assert np.array_equal(pk, exp), tile
+    # four passes in flight (the bench's mode; the default tile becomes W = 8 here): every held pass
+    plan = engine.WavePlan(eng, ss, 100, 10, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS)
+    plan.set_depth(4)
+    plan.run_n(103)
+    for age in range(4):
+        plan.select(age)
+        assert np.array_equal(plan.peaks(), exp), age
+    plan.close()
     ss.close()
 
 
