@@ -58,6 +58,10 @@ def load():
     L.gams_host_encode_gz.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.gams_host_loader_records.restype = C.c_void_p
     L.gams_host_loader_records.argtypes = [C.c_void_p, C.c_uint32, sp, sp, ip, ip, C.c_char_p, C.c_char_p]
+    L.gams_host_count_multi.restype = C.c_int
+    L.gams_host_count_multi.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p]
+    L.gams_host_cover_multi.restype = C.c_int
+    L.gams_host_cover_multi.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 8 + [C.c_uint64, C.c_void_p]
     L.gams_host_header.restype = C.c_void_p
     L.gams_host_header.argtypes = [C.c_int]
     L.gams_host_tsv_ctgs.restype = C.c_void_p
@@ -200,6 +204,37 @@ def loader_records(eng, ctgs, lines, tag=None):
     out = _take(load().gams_host_loader_records(eng.h, n, ids, chrs, st.ctypes.data, en.ctypes.data,
                                                 "\n".join(lines).encode(), tag.encode() if tag is not None else None))
     return [tuple(r.split("\t", 1)) for r in out.splitlines()]
+
+
+def _check_rc(rc):
+    if rc != 0:
+        L = load()
+        raise HostError(L.gams_host_last_code(), L.gams_host_last_error().decode(errors="replace"))
+
+
+def count_multi(engines, group_off, starts, stops, q_group, qs, qe):
+    """`locate --count` over several handles: groups split by LPT, queries routed to their group's device."""
+    hs = (C.c_void_p * len(engines))(*[e.h.value for e in engines])
+    group_off = np.ascontiguousarray(group_off, np.uint64)
+    a = [np.ascontiguousarray(x, np.uint32) for x in (starts, stops, q_group, qs, qe)]
+    out = np.zeros(a[2].size, np.int32)
+    _check_rc(load().gams_host_count_multi(hs, len(engines), group_off.size - 1, group_off.ctypes.data,
+                                           *[x.ctypes.data for x in a], a[2].size, out.ctypes.data))
+    return out
+
+
+def cover_multi(engines, group_off, lo, hi, q_group, clip_lo, clip_hi, qs, qe):
+    """`anno` coverage over several handles (groups = chromosomes of the runlist set)."""
+    hs = (C.c_void_p * len(engines))(*[e.h.value for e in engines])
+    group_off = np.ascontiguousarray(group_off, np.uint64)
+    lo, hi = np.ascontiguousarray(lo, np.int32), np.ascontiguousarray(hi, np.int32)
+    q_group = np.ascontiguousarray(q_group, np.uint32)
+    b = [np.ascontiguousarray(x, np.int32) for x in (clip_lo, clip_hi, qs, qe)]
+    out = np.zeros(q_group.size, np.float32)
+    _check_rc(load().gams_host_cover_multi(hs, len(engines), group_off.size - 1, group_off.ctypes.data, lo.ctypes.data,
+                                           hi.ctypes.data, q_group.ctypes.data, *[x.ctypes.data for x in b],
+                                           q_group.size, out.ctypes.data))
+    return out
 
 
 def header(command):

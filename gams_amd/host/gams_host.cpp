@@ -386,6 +386,127 @@ std::vector<uint32_t> lpt_assign(const std::vector<uint64_t> &weights, uint32_t 
     return owner;
 }
 
+namespace {
+
+// what one device owns of a sharded interval problem: its groups (renumbered 0..), its queries
+struct IntervalShare {
+    std::vector<uint32_t> groups;       // global group ids, ascending
+    std::vector<uint64_t> off;          // local group_off
+    std::vector<uint64_t> q;            // global query indices, in query order
+};
+
+// groups -> owners by LPT on their sizes; queries follow their group
+std::vector<IntervalShare> shard_intervals(uint32_t n_owners, uint32_t n_groups, const uint64_t *group_off,
+                                           const uint32_t *q_group, uint64_t nq, std::vector<uint32_t> &local_id) {
+    std::vector<uint64_t> weight(n_groups);
+    for (uint32_t g = 0; g < n_groups; ++g) weight[g] = group_off[g + 1] - group_off[g] + 1;
+    const std::vector<uint32_t> owner = lpt_assign(weight, n_owners);
+    std::vector<IntervalShare> sh(n_owners);
+    local_id.assign(n_groups, 0);
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        IntervalShare &s = sh[owner[g]];
+        local_id[g] = (uint32_t)s.groups.size();
+        if (s.off.empty()) s.off.push_back(0);
+        s.groups.push_back(g);
+        s.off.push_back(s.off.back() + (group_off[g + 1] - group_off[g]));
+    }
+    for (auto &s : sh)
+        if (s.off.empty()) s.off.push_back(0);
+    for (uint64_t i = 0; i < nq; ++i)
+        if (q_group[i] < n_groups) sh[owner[q_group[i]]].q.push_back(i);
+    return sh;
+}
+
+template <typename F>
+void run_shares(uint32_t n, F fn) {
+    std::vector<std::exception_ptr> errs(n);
+    std::vector<std::thread> pool;
+    for (uint32_t g = 0; g < n; ++g)
+        pool.emplace_back([&, g] {
+            try {
+                fn(g);
+            } catch (...) {
+                errs[g] = std::current_exception();
+            }
+        });
+    for (auto &t : pool) t.join();
+    for (auto &e : errs)
+        if (e) std::rethrow_exception(e);
+}
+
+}  // namespace
+
+void count_multi(const std::vector<gams_gpu_t *> &handles, uint32_t n_groups, const uint64_t *group_off,
+                 const uint32_t *starts, const uint32_t *stops, const uint32_t *q_group, const uint32_t *qs,
+                 const uint32_t *qe, uint64_t nq, int32_t *count) {
+    if (handles.empty()) throw Error(GAMS_EINVAL, "count_multi: no handles");
+    std::vector<uint32_t> local_id;
+    const std::vector<IntervalShare> sh = shard_intervals((uint32_t)handles.size(), n_groups, group_off, q_group, nq, local_id);
+    for (uint64_t i = 0; i < nq; ++i)
+        if (q_group[i] >= n_groups) count[i] = 0;                        // utils.rs:29-32: ctg without an index
+    run_shares((uint32_t)handles.size(), [&](uint32_t d) {
+        const IntervalShare &s = sh[d];
+        if (s.q.empty()) return;
+        gams_gpu_t *h = handles[d];
+        std::vector<uint32_t> st, sp;
+        for (uint32_t g : s.groups) {
+            st.insert(st.end(), starts + group_off[g], starts + group_off[g + 1]);
+            sp.insert(sp.end(), stops + group_off[g], stops + group_off[g + 1]);
+        }
+        gams_index_t *ix = nullptr;
+        check(h, gams_index_create(h, (uint32_t)s.groups.size(), s.off.data(), st.data(), sp.data(), &ix));
+        std::vector<uint32_t> g(s.q.size()), a(s.q.size()), b(s.q.size());
+        for (size_t k = 0; k < s.q.size(); ++k) {
+            g[k] = local_id[q_group[s.q[k]]];
+            a[k] = qs[s.q[k]];
+            b[k] = qe[s.q[k]];
+        }
+        std::vector<int32_t> out(s.q.size());
+        const int rc = gams_gpu_count(h, ix, g.data(), a.data(), b.data(), s.q.size(), out.data());
+        gams_index_destroy(h, ix);
+        check(h, rc);
+        for (size_t k = 0; k < s.q.size(); ++k) count[s.q[k]] = out[k];
+    });
+}
+
+void cover_multi(const std::vector<gams_gpu_t *> &handles, uint32_t n_groups, const uint64_t *group_off,
+                 const int32_t *lo, const int32_t *hi, const uint32_t *q_group, const int32_t *clip_lo,
+                 const int32_t *clip_hi, const int32_t *qs, const int32_t *qe, uint64_t nq, float *prop) {
+    if (handles.empty()) throw Error(GAMS_EINVAL, "cover_multi: no handles");
+    std::vector<uint32_t> local_id;
+    const std::vector<IntervalShare> sh = shard_intervals((uint32_t)handles.size(), n_groups, group_off, q_group, nq, local_id);
+    for (uint64_t i = 0; i < nq; ++i)
+        if (q_group[i] >= n_groups) prop[i] = 0.0f;                      // anno.rs:128: chr absent from the set
+    run_shares((uint32_t)handles.size(), [&](uint32_t d) {
+        const IntervalShare &s = sh[d];
+        if (s.q.empty()) return;
+        gams_gpu_t *h = handles[d];
+        std::vector<int32_t> l, u;
+        for (uint32_t g : s.groups) {
+            l.insert(l.end(), lo + group_off[g], lo + group_off[g + 1]);
+            u.insert(u.end(), hi + group_off[g], hi + group_off[g + 1]);
+        }
+        gams_spans_t *sp = nullptr;
+        check(h, gams_spans_create(h, (uint32_t)s.groups.size(), s.off.data(), l.data(), u.data(), &sp));
+        const size_t m = s.q.size();
+        std::vector<uint32_t> g(m);
+        std::vector<int32_t> cl(m), ch(m), a(m), b(m);
+        for (size_t k = 0; k < m; ++k) {
+            const uint64_t i = s.q[k];
+            g[k] = local_id[q_group[i]];
+            cl[k] = clip_lo[i];
+            ch[k] = clip_hi[i];
+            a[k] = qs[i];
+            b[k] = qe[i];
+        }
+        std::vector<float> out(m);
+        const int rc = gams_gpu_cover(h, sp, g.data(), cl.data(), ch.data(), a.data(), b.data(), m, out.data());
+        gams_spans_destroy(h, sp);
+        check(h, rc);
+        for (size_t k = 0; k < m; ++k) prop[s.q[k]] = out[k];
+    });
+}
+
 std::vector<std::string> wave_proc_ctgs_multi(const std::vector<gams_gpu_t *> &handles, const std::vector<Ctg> &ctgs,
                                               const std::vector<const uint8_t *> &seqs, const WaveArgs &a,
                                               uint64_t batch_bytes) {

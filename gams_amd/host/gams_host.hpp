@@ -82,6 +82,19 @@ std::vector<std::string> wave_proc_ctgs_multi(const std::vector<gams_gpu_t *> &h
 // longest-processing-time-first assignment (weights -> owner per item); ties by index
 std::vector<uint32_t> lpt_assign(const std::vector<uint64_t> &weights, uint32_t n_owners);
 
+// `locate --count` / `anno` over several devices: the groups (ctgs, or chromosomes of
+// the runlist set) are split over the handles by longest-processing-time-first on their interval
+// counts, every query is routed to the device that owns its group (a counting sort on the host:
+// the only "exchange step" of the path), one host thread per handle runs its share, and the
+// results scatter back to the query order.  Same arguments as gams_gpu_count / gams_gpu_cover with
+// the index given as arrays; queries of unknown groups (>= n_groups) get 0.
+void count_multi(const std::vector<gams_gpu_t *> &handles, uint32_t n_groups, const uint64_t *group_off,
+                 const uint32_t *starts, const uint32_t *stops, const uint32_t *q_group, const uint32_t *qs,
+                 const uint32_t *qe, uint64_t nq, int32_t *count);
+void cover_multi(const std::vector<gams_gpu_t *> &handles, uint32_t n_groups, const uint64_t *group_off,
+                 const int32_t *lo, const int32_t *hi, const uint32_t *q_group, const int32_t *clip_lo,
+                 const int32_t *clip_hi, const int32_t *qs, const int32_t *qe, uint64_t nq, float *prop);
+
 // sw.rs:108-194
 std::string sw_proc_ctg(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq, const std::vector<Feature> &features,
                         const SwArgs &a);

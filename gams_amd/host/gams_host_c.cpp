@@ -311,6 +311,33 @@ char *gams_host_tsv_ctgs(uint32_t n, const char *const *ids, const char *const *
 // header lines of `gams wave` (which == 0) and `gams sw` (which == 1)
 char *gams_host_header(int which) { return dup(which == 0 ? gams::wave_header() : gams::sw_header()); }
 
+// locate --count / anno coverage over several handles (one per GPU)
+int gams_host_count_multi(gams_gpu_t *const *handles, uint32_t n_handles, uint32_t n_groups, const uint64_t *group_off,
+                          const uint32_t *starts, const uint32_t *stops, const uint32_t *q_group, const uint32_t *qs,
+                          const uint32_t *qe, uint64_t nq, int32_t *count) {
+    char *r = guarded([&] {
+        gams::count_multi(std::vector<gams_gpu_t *>(handles, handles + n_handles), n_groups, group_off, starts, stops,
+                          q_group, qs, qe, nq, count);
+        return std::string();
+    });
+    if (!r) return g_code ? g_code : -1;
+    free(r);
+    return 0;
+}
+
+int gams_host_cover_multi(gams_gpu_t *const *handles, uint32_t n_handles, uint32_t n_groups, const uint64_t *group_off,
+                          const int32_t *lo, const int32_t *hi, const uint32_t *q_group, const int32_t *clip_lo,
+                          const int32_t *clip_hi, const int32_t *qs, const int32_t *qe, uint64_t nq, float *prop) {
+    char *r = guarded([&] {
+        gams::cover_multi(std::vector<gams_gpu_t *>(handles, handles + n_handles), n_groups, group_off, lo, hi, q_group,
+                          clip_lo, clip_hi, qs, qe, nq, prop);
+        return std::string();
+    });
+    if (!r) return g_code ? g_code : -1;
+    free(r);
+    return 0;
+}
+
 // formatting helpers exposed for CPU-only tests
 char *gams_host_fmt_f32(float v) { return dup(gams::fmt_f32(v)); }
 char *gams_host_range_roundtrip(const char *s) {

@@ -135,3 +135,51 @@ def test_cover_on_skewed_and_negative_spans(eng):
         slo, shi = sets[g[i]]
         exp = ora.anno_prop(slo, shi, int(cl[i]), int(ch[i]), int(s[i]), int(e[i]))
         assert prop[i] == np.float32(exp), (i, g[i], s[i], e[i], cl[i], ch[i])
+
+
+@pytest.mark.parametrize("n_handles", [1, 2, 3])
+def test_count_and_cover_sharded_over_handles_equal_single(eng, n_handles):
+    """SURVEY 8e for the interval path: groups split over the handles (LPT), queries routed to the owner, results
+    scattered back -- identical to one handle holding everything."""
+    from gams_amd import host
+
+    rng = np.random.default_rng(500 + n_handles)
+    groups = _groups(rng)
+    off = np.cumsum([0] + [g[0].size for g in groups]).astype(np.uint64)
+    starts = np.concatenate([g[0] for g in groups]).astype(np.uint32)
+    stops = np.concatenate([g[1] for g in groups]).astype(np.uint32)
+    qg, qs, qe = _queries(rng, groups, 400)
+    engs = [eng] + [engine.Engine(0) for _ in range(n_handles - 1)]
+    got = host.count_multi(engs, off, starts, stops, qg, qs, qe)
+    ix = C.c_void_p()
+    eng.check(eng.lib.gams_index_create(eng.h, len(groups), off.ctypes.data, starts.ctypes.data, stops.ctypes.data,
+                                        C.byref(ix)))
+    exp = np.zeros(qg.size, np.int32)
+    eng.check(eng.lib.gams_gpu_count(eng.h, ix, qg.ctypes.data, qs.ctypes.data, qe.ctypes.data, qg.size, exp.ctypes.data))
+    eng.lib.gams_index_destroy(eng.h, ix)
+    assert np.array_equal(got, exp)
+    # cover
+    sets = []
+    for k in range(7):
+        m = int(rng.choice([0, 1, 40, 3000]))
+        cuts = np.sort(rng.choice(np.arange(-100000, 100000, 2), 2 * m, replace=False)) if m else np.zeros(0, np.int64)
+        sets.append((cuts[0::2].astype(np.int32), (cuts[1::2] - 1).astype(np.int32)))
+    soff = np.cumsum([0] + [s[0].size for s in sets]).astype(np.uint64)
+    lo = np.concatenate([s[0] for s in sets]).astype(np.int32)
+    hi = np.concatenate([s[1] for s in sets]).astype(np.int32)
+    n = 5000
+    g = rng.integers(0, len(sets) + 1, n).astype(np.uint32)
+    s = rng.integers(-101000, 101000, n).astype(np.int32)
+    e = (s + rng.choice([0, 9, 500, 40000], n)).astype(np.int32)
+    cl = (s - rng.choice([0, 100, 10**6], n)).astype(np.int32)
+    ch = (e + rng.choice([-1, 0, 10**6], n)).astype(np.int32)
+    got = host.cover_multi(engs, soff, lo, hi, g, cl, ch, s, e)
+    sp = C.c_void_p()
+    eng.check(eng.lib.gams_spans_create(eng.h, len(sets), soff.ctypes.data, lo.ctypes.data, hi.ctypes.data, C.byref(sp)))
+    exp = np.zeros(n, np.float32)
+    eng.check(eng.lib.gams_gpu_cover(eng.h, sp, g.ctypes.data, cl.ctypes.data, ch.ctypes.data, s.ctypes.data,
+                                     e.ctypes.data, n, exp.ctypes.data))
+    eng.lib.gams_spans_destroy(eng.h, sp)
+    assert np.array_equal(got, exp)
+    for x in engs[1:]:
+        x.close()
