@@ -62,6 +62,9 @@ def load():
     L.gams_host_count_multi.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p]
     L.gams_host_cover_multi.restype = C.c_int
     L.gams_host_cover_multi.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 8 + [C.c_uint64, C.c_void_p]
+    L.gams_host_sw_multi.restype = C.c_void_p
+    L.gams_host_sw_multi.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, sp, sp, ip, ip, C.c_void_p, C.c_char_p,
+                                     C.c_int32, C.c_int32, C.c_int32]
     L.gams_host_header.restype = C.c_void_p
     L.gams_host_header.argtypes = [C.c_int]
     L.gams_host_tsv_ctgs.restype = C.c_void_p
@@ -204,6 +207,18 @@ def loader_records(eng, ctgs, lines, tag=None):
     out = _take(load().gams_host_loader_records(eng.h, n, ids, chrs, st.ctypes.data, en.ctypes.data,
                                                 "\n".join(lines).encode(), tag.encode() if tag is not None else None))
     return [tuple(r.split("\t", 1)) for r in out.splitlines()]
+
+
+def sw_multi(engines, ctgs, features_per_ctg, size=100, mx=20, resize=500):
+    """`gams sw` over several handles; features_per_ctg[i] = list of (id, start, end) of ctgs[i]."""
+    n, ids, chrs, st, en = _ctg_arrays(ctgs)
+    bufs = [np.ascontiguousarray(np.frombuffer(c["seq"], np.uint8) if not isinstance(c["seq"], np.ndarray)
+                                 else c["seq"]) for c in ctgs]
+    seqs = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in bufs])
+    hs = (C.c_void_p * len(engines))(*[e.h.value for e in engines])
+    rows = "\n".join(f"{i}\t{fid}\t{s}\t{e}" for i, fl in enumerate(features_per_ctg) for fid, s, e in fl)
+    return _take(load().gams_host_sw_multi(hs, len(engines), n, ids, chrs, st.ctypes.data, en.ctypes.data, seqs,
+                                           rows.encode(), size, mx, resize))
 
 
 def _check_rc(rc):

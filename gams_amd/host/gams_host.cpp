@@ -436,6 +436,23 @@ void run_shares(uint32_t n, F fn) {
 
 }  // namespace
 
+std::vector<std::string> sw_proc_ctgs_multi(const std::vector<gams_gpu_t *> &handles, const std::vector<Ctg> &ctgs,
+                                            const std::vector<const uint8_t *> &seqs,
+                                            const std::vector<std::vector<Feature>> &features, const SwArgs &a) {
+    if (handles.empty()) throw Error(GAMS_EINVAL, "sw_proc_ctgs_multi: no handles");
+    if (ctgs.size() != seqs.size() || ctgs.size() != features.size())
+        throw Error(GAMS_EINVAL, "sw_proc_ctgs_multi: ctgs / seqs / features size mismatch");
+    std::vector<uint64_t> weight(ctgs.size());
+    for (size_t c = 0; c < ctgs.size(); ++c) weight[c] = features[c].size() + 1;
+    const std::vector<uint32_t> owner = lpt_assign(weight, (uint32_t)handles.size());
+    std::vector<std::string> out(ctgs.size());
+    run_shares((uint32_t)handles.size(), [&](uint32_t d) {
+        for (size_t c = 0; c < ctgs.size(); ++c)
+            if (owner[c] == d && !features[c].empty()) out[c] = sw_proc_ctg(handles[d], ctgs[c], seqs[c], features[c], a);
+    });
+    return out;
+}
+
 void count_multi(const std::vector<gams_gpu_t *> &handles, uint32_t n_groups, const uint64_t *group_off,
                  const uint32_t *starts, const uint32_t *stops, const uint32_t *q_group, const uint32_t *qs,
                  const uint32_t *qe, uint64_t nq, int32_t *count) {

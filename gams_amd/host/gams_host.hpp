@@ -98,6 +98,11 @@ void cover_multi(const std::vector<gams_gpu_t *> &handles, uint32_t n_groups, co
 // sw.rs:108-194
 std::string sw_proc_ctg(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq, const std::vector<Feature> &features,
                         const SwArgs &a);
+// `gams sw --parallel` over several devices: ctgs split over the handles by LPT on their feature
+// counts, one host thread per handle, rows returned per ctg in the order given.
+std::vector<std::string> sw_proc_ctgs_multi(const std::vector<gams_gpu_t *> &handles, const std::vector<Ctg> &ctgs,
+                                            const std::vector<const uint8_t *> &seqs,
+                                            const std::vector<std::vector<Feature>> &features, const SwArgs &a);
 
 // idx:ctg: / idx:rg: on the device (redis.rs:236-324) + the locate loop (locate.rs:111-141)
 class Locator {

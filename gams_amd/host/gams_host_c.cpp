@@ -121,6 +121,34 @@ char *gams_host_sw(gams_gpu_t *h, const char *ctg_id, const char *chr, int32_t c
     });
 }
 
+// `gams sw` over several handles.  features: rows "ctg_index\tfeature_id\tstart\tend"
+char *gams_host_sw_multi(gams_gpu_t *const *handles, uint32_t n_handles, uint32_t n, const char *const *ids,
+                         const char *const *chrs, const int32_t *starts, const int32_t *ends,
+                         const uint8_t *const *seqs, const char *features, int32_t size, int32_t max, int32_t resize) {
+    return guarded([&] {
+        std::vector<std::vector<gams::Feature>> f(n);
+        for (const std::string &ln : split_lines(features)) {
+            std::istringstream is(ln);
+            std::string ci, id, s0, s1;
+            std::getline(is, ci, '\t');
+            std::getline(is, id, '\t');
+            std::getline(is, s0, '\t');
+            std::getline(is, s1, '\t');
+            f.at((size_t)std::stoul(ci)).push_back(gams::Feature{id, std::stoi(s0), std::stoi(s1)});
+        }
+        gams::SwArgs a;
+        a.size = size;
+        a.max = max;
+        a.resize = resize;
+        std::string out;
+        for (auto &s : gams::sw_proc_ctgs_multi(std::vector<gams_gpu_t *>(handles, handles + n_handles),
+                                                make_ctgs(n, ids, chrs, starts, ends),
+                                                std::vector<const uint8_t *>(seqs, seqs + n), f, a))
+            out += s;
+        return out;
+    });
+}
+
 // locate.rs:111-141.  rgs: newline-separated ranges (first TSV column already cut).
 // rg_lines (for --count): newline-separated "ctg_id\trange" rows = the rg: records per ctg.
 char *gams_host_locate(gams_gpu_t *h, uint32_t n, const char *const *ids, const char *const *chrs,

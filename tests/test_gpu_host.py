@@ -384,3 +384,17 @@ def test_sw_rejects_one_bp_windows(eng, s288c):
         with pytest.raises(Exception) as ei:
             host.sw(eng, c, feats, size, 20, resize)
         assert "size >= 2" in str(ei.value)
+
+
+@pytest.mark.parametrize("n_handles", [1, 2, 3])
+def test_sw_multi_handles_equals_per_ctg(eng, s288c, n_handles):
+    """`gams sw --parallel` over several handles (ctgs split by LPT on their feature counts)"""
+    ctgs = all_ctgs(s288c)
+    buckets = bucket_features(s288c, ctgs)
+    feats = [[(f"feature:{c['id']}:{i + 1}", s, e) for i, (s, e) in enumerate(buckets.get(c["id"], []))] for c in ctgs]
+    exp = "".join(ora.sw_proc_ctg(c["chr_id"], c["chr_start"], c["chr_end"], c["seq"], f) for c, f in zip(ctgs, feats) if f)
+    engs = [eng] + [engine.Engine(0) for _ in range(n_handles - 1)]
+    got = host.sw_multi(engs, ctgs, feats)
+    for x in engs[1:]:
+        x.close()
+    assert got == exp
