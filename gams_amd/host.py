@@ -252,6 +252,20 @@ def cover_multi(engines, group_off, lo, hi, q_group, clip_lo, clip_hi, qs, qe):
     return out
 
 
+def merge_windows(windows, chr_start, size, step, coverage):
+    """merge_ints (wave.rs:217-252) of ascending window indices: (component min, component max, has-an-edge)"""
+    L = load()
+    w = np.ascontiguousarray(windows, np.uint32)
+    cmin, cmax = np.zeros(w.size, np.int64), np.zeros(w.size, np.int64)
+    ing = np.zeros(w.size, np.int8)
+    L.gams_host_merge_windows.restype = None
+    L.gams_host_merge_windows.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gams_host_merge_windows(w.ctypes.data, w.size, chr_start, size, step, coverage, cmin.ctypes.data,
+                              cmax.ctypes.data, ing.ctypes.data)
+    return cmin, cmax, ing.astype(bool)
+
+
 def header(command):
     """the header line `gams wave` / `gams sw` print before the rows"""
     return _take(load().gams_host_header(0 if command == "wave" else 1))

@@ -213,6 +213,16 @@ Merge merge_ints(const std::vector<uint32_t> &w, int32_t chr_start, int32_t size
 
 }  // namespace
 
+void merge_windows(const uint32_t *w, size_t n, int32_t chr_start, int32_t size, int32_t step, float coverage,
+                   int64_t *cmin, int64_t *cmax, char *in_graph) {
+    const Merge m = merge_ints(std::vector<uint32_t>(w, w + n), chr_start, size, step, coverage);
+    for (size_t i = 0; i < n; ++i) {
+        cmin[i] = m.cmin[i];
+        cmax[i] = m.cmax[i];
+        in_graph[i] = m.in_graph[i];
+    }
+}
+
 namespace {
 
 // One batch of ctgs in flight on one handle: start() queues the uploads (copy stream) and the

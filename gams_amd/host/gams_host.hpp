@@ -81,6 +81,10 @@ std::vector<std::string> wave_proc_ctgs_multi(const std::vector<gams_gpu_t *> &h
                                               uint64_t batch_bytes = 1ull << 30);
 // longest-processing-time-first assignment (weights -> owner per item); ties by index
 std::vector<uint32_t> lpt_assign(const std::vector<uint64_t> &weights, uint32_t n_owners);
+// merge_ints (wave.rs:217-252) over the ascending window indices of one sign of one ctg: the merged
+// component's chromosome span per window, and whether the window has any edge (is printed as "(+)").
+void merge_windows(const uint32_t *w, size_t n, int32_t chr_start, int32_t size, int32_t step, float coverage,
+                   int64_t *cmin, int64_t *cmax, char *in_graph);
 
 // `locate --count` / `anno` over several devices: the groups (ctgs, or chromosomes of
 // the runlist set) are split over the handles by longest-processing-time-first on their interval

@@ -366,6 +366,12 @@ int gams_host_cover_multi(gams_gpu_t *const *handles, uint32_t n_handles, uint32
     return 0;
 }
 
+// merge_ints of wave.rs:217-252, for CPU-only tests of the host logic
+void gams_host_merge_windows(const uint32_t *w, uint64_t n, int32_t chr_start, int32_t size, int32_t step,
+                             float coverage, int64_t *cmin, int64_t *cmax, char *in_graph) {
+    gams::merge_windows(w, (size_t)n, chr_start, size, step, coverage, cmin, cmax, in_graph);
+}
+
 // formatting helpers exposed for CPU-only tests
 char *gams_host_fmt_f32(float v) { return dup(gams::fmt_f32(v)); }
 char *gams_host_range_roundtrip(const char *s) {

@@ -79,3 +79,44 @@ def test_command_headers():
     assert host.header("wave").rstrip("\n") == helpers.read_lines("I.peaks.tsv")[0]
     assert host.header("sw").rstrip("\n").split("\t") == ["id", "range", "type", "distance", "gc_content", "gc_mean",
                                                            "gc_stddev", "gc_cv", "rg_count"]
+
+
+def test_merge_ints_against_the_pairwise_rule():
+    """wave.rs:217-252 restated pair by pair (every i<j: non-empty intersection, size/|cap| >= coverage on both
+    sides, f32 like the reference; components by union-find) against the host's distance-range merge."""
+    rng = np.random.default_rng(12)
+    for it in range(300):
+        size = int(rng.choice([10, 50, 100, 100, 255, 1000]))
+        step = int(rng.choice([1, 5, 10, 10, 33, 100, 150, 999]))
+        cov = float(rng.choice([0.05, 0.2, 0.2, 0.5, 1.0, 1.05, 1.5, 3.0]))
+        n = int(rng.integers(0, 60))
+        w = np.unique(rng.integers(0, 40 + n * rng.choice([1, 3, 30]), n)).astype(np.uint32)
+        chr_start = int(rng.integers(1, 10**6))
+        cmin, cmax, ing = host.merge_windows(w, chr_start, size, step, cov)
+        s = chr_start + w.astype(np.int64) * step
+        e = s + size - 1
+        par = list(range(w.size))
+
+        def find(x):
+            while par[x] != x:
+                par[x] = par[par[x]]
+                x = par[x]
+            return x
+
+        edge = np.zeros(w.size, bool)
+        for i in range(w.size):
+            for j in range(i + 1, w.size):
+                inter = min(e[i], e[j]) - max(s[i], s[j]) + 1
+                if inter <= 0:
+                    continue
+                c = np.float32(size) / np.float32(inter)
+                if c >= np.float32(cov):
+                    edge[i] = edge[j] = True
+                    a, b = find(i), find(j)
+                    if a != b:
+                        par[b] = a
+        roots = [find(i) for i in range(w.size)]
+        for i in range(w.size):
+            members = [k for k in range(w.size) if roots[k] == roots[i]]
+            assert cmin[i] == min(s[k] for k in members) and cmax[i] == max(e[k] for k in members), (it, i)
+        assert np.array_equal(ing, edge), it
