@@ -285,11 +285,19 @@ std::vector<std::string> WaveJob::finish() {
     if (n == 0) return out;
     const float fsize = (float)a.size;
     if (a.signal) {                                                     // wave.rs:158-168
+        // fetch the dense rows on this thread (the handle's), format the ctgs on several
+        std::vector<std::vector<uint32_t>> cnts(n);
+        std::vector<std::vector<int8_t>> sigs(n);
         for (uint32_t c = 0; c < n; ++c) {
             const uint32_t nw = gams_wave_ctg_windows(pg.p, c);
-            std::vector<uint32_t> cnt(nw ? nw : 1);
-            std::vector<int8_t> sig(nw ? nw : 1);
-            check(h, gams_wave_dense(h, pg.p, c, cnt.data(), sig.data()));
+            cnts[c].resize(nw ? nw : 1);
+            sigs[c].resize(nw ? nw : 1);
+            check(h, gams_wave_dense(h, pg.p, c, cnts[c].data(), sigs[c].data()));
+        }
+        parallel_for(n, [&](uint32_t c) {
+            const uint32_t nw = gams_wave_ctg_windows(pg.p, c);
+            const std::vector<uint32_t> &cnt = cnts[c];
+            const std::vector<int8_t> &sig = sigs[c];
             std::string &o = out[c];
             o.reserve((size_t)nw * 24);
             for (uint32_t i = 0; i < nw; ++i) {
@@ -303,7 +311,7 @@ std::vector<std::string> WaveJob::finish() {
                 o += std::to_string((int)sig[i]);
                 o += '\n';
             }
-        }
+        });
         return out;
     }
     const gams_peak_t *pk = nullptr;
