@@ -333,7 +333,10 @@ hipError_t gams_pool_alloc(gams_gpu_t *h, bool pinned, size_t bytes, void **out,
         pool.clear();
         e = pinned ? hipHostMalloc(out, want, hipHostMallocDefault) : hipMalloc(out, want);
     }
-    if (e == hipSuccess) *cap = want;
+    if (e == hipSuccess)
+        *cap = want;
+    else
+        (void)hipGetLastError();   // the failure is reported through `e`; do not leave it sticky for the next launch check
     return e;
 }
 

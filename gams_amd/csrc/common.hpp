@@ -51,6 +51,7 @@ hipError_t gams_pool_alloc(gams_gpu_t *h, bool pinned, size_t bytes, void **out,
 void gams_pool_free(gams_gpu_t *h, bool pinned, void *p, size_t cap);
 
 inline int gams_fail(gams_gpu_t *h, int code, const std::string &msg) {
+    (void)hipGetLastError();   // a failed HIP call is reported through the code; it must not stay sticky
     if (h) {
         std::lock_guard<std::mutex> lk(h->err_mu);   // gams_wave_run_n queues from two host threads
         h->err = msg;
@@ -62,6 +63,7 @@ inline int gams_fail(gams_gpu_t *h, int code, const std::string &msg) {
     do {                                                                            \
         hipError_t e_ = (call);                                                     \
         if (e_ != hipSuccess) {                                                     \
+            (void)hipGetLastError(); /* reported here; not left sticky */           \
             return gams_fail((h), GAMS_EHIP,                                        \
                              std::string(#call) + ": " + hipGetErrorString(e_));    \
         }                                                                           \

@@ -320,6 +320,7 @@ int gams_index_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
     if (e == hipSuccess) e = to_device(&ix->d_dir_start, dir_s.data(), dir_s.size());
     if (e == hipSuccess) e = to_device(&ix->d_dir_stop, dir_t.data(), dir_t.size());
     if (e != hipSuccess) {
+        (void)hipGetLastError();   // reported below, not left sticky
         gams_index_destroy(h, ix);
         return gams_fail(h, e == hipErrorOutOfMemory ? GAMS_ENOMEM : GAMS_EHIP,
                          std::string("index_create: ") + hipGetErrorString(e));
@@ -439,6 +440,7 @@ int gams_spans_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
     if (e == hipSuccess) e = to_device(&sp->d_rec, rec.data(), m);
     if (e == hipSuccess) e = to_device(&sp->d_dir_lo, dir.data(), dir.size());
     if (e != hipSuccess) {
+        (void)hipGetLastError();
         gams_spans_destroy(h, sp);
         return gams_fail(h, e == hipErrorOutOfMemory ? GAMS_ENOMEM : GAMS_EHIP,
                          std::string("spans_create: ") + hipGetErrorString(e));

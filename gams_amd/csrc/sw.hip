@@ -299,6 +299,7 @@ int gams_seqset_gcindex(gams_gpu_t *h, gams_seqset_t *s) {
     hipError_t e = hipMalloc(&ix->d_pm, ix->n_chunks * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&ix->d_seg, (ix->n_segs + 1) * sizeof(uint64_t));
     if (e != hipSuccess) {
+        (void)hipGetLastError();   // reported below, not left sticky
         (void)hipFree(ix->d_pm);
         (void)hipFree(ix->d_seg);
         delete ix;
@@ -309,6 +310,7 @@ int gams_seqset_gcindex(gams_gpu_t *h, gams_seqset_t *s) {
     hipLaunchKernelGGL(gc_index_scan, dim3(1), dim3(256), 0, h->compute, ix->d_seg, ix->n_segs);
     e = hipGetLastError();
     if (e != hipSuccess) {
+        (void)hipGetLastError();   // reported below, not left sticky
         (void)hipFree(ix->d_pm);
         (void)hipFree(ix->d_seg);
         delete ix;

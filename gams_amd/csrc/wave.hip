@@ -425,6 +425,7 @@ int gams_wave_plan_create(gams_gpu_t *h, gams_seqset_t *s, const gams_wave_param
     do {                                                                                  \
         hipError_t e_ = (call);                                                           \
         if (e_ != hipSuccess) {                                                           \
+            (void)hipGetLastError();                                                      \
             h->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
             return fail(GAMS_EHIP);                                                       \
         }                                                                                 \

@@ -389,3 +389,15 @@ def test_block_pool_is_reused_and_can_be_released(eng, s288c):
     eng.check(eng.lib.gams_gpu_release_cached(eng.h, C.byref(held)))
     assert held.value == 0
     check_dense(eng, s288c["Mito"][:30000], 100, 10, 100, 3.0)   # and the handle keeps working
+
+
+def test_out_of_memory_is_reported_and_survivable(eng, s288c):
+    """a seqset beyond the HBM: GAMS_ENOMEM, and the handle keeps working afterwards"""
+    import ctypes as C
+
+    lens = np.full(120, 4_000_000_000, np.uint32)        # 480 GB
+    p = C.c_void_p()
+    rc = eng.lib.gams_seqset_create(eng.h, lens.size, lens.ctypes.data, C.byref(p))
+    assert rc == _lib.ENOMEM, rc
+    assert b"hipMalloc" in eng.lib.gams_gpu_last_error(eng.h)
+    check_dense(eng, s288c["Mito"][:30000], 100, 10, 100, 3.0)
