@@ -401,3 +401,28 @@ def test_out_of_memory_is_reported_and_survivable(eng, s288c):
     assert rc == _lib.ENOMEM, rc
     assert b"hipMalloc" in eng.lib.gams_gpu_last_error(eng.h)
     check_dense(eng, s288c["Mito"][:30000], 100, 10, 100, 3.0)
+
+
+def test_call_order_and_argument_errors(eng, s288c):
+    """status codes instead of panics: results before a run, wrong outputs for the plan's flags, bad indices"""
+    import ctypes as C
+
+    ss = engine.SeqSet(eng, [bytes(s288c["Mito"][:30000])])
+    plan = engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS)
+    pk, n = C.c_void_p(), C.c_uint64()
+    assert eng.lib.gams_wave_peaks(eng.h, plan.p, C.byref(pk), C.byref(n)) == _lib.ESTATE       # nothing ran yet
+    assert eng.lib.gams_wave_plan_select(eng.h, plan.p, 0) == _lib.ESTATE
+    plan.run()
+    cnt = np.zeros(4000, np.uint32)
+    assert eng.lib.gams_wave_dense(eng.h, plan.p, 0, cnt.ctypes.data, None) == _lib.ESTATE      # no DENSE output
+    assert eng.lib.gams_wave_plan_set_depth(eng.h, plan.p, 0) == _lib.EINVAL
+    assert eng.lib.gams_wave_plan_set_depth(eng.h, plan.p, 5) == _lib.EINVAL
+    assert eng.lib.gams_wave_plan_select(eng.h, plan.p, 1) == _lib.ESTATE                       # depth 1 holds one run
+    assert eng.lib.gams_seqset_upload(eng.h, ss.p, 3, cnt.ctypes.data) == _lib.EINVAL           # ctg index
+    prm = _lib.WaveParams(0, 10, 100, 3.0, 1.0) if hasattr(_lib, "WaveParams") else None
+    if prm is not None:
+        bad = C.c_void_p()
+        assert eng.lib.gams_wave_plan_create(eng.h, ss.p, C.byref(prm), _lib.WAVE_PEAKS, C.byref(bad)) == _lib.EINVAL
+    assert plan.peaks().size > 0                                                               # still fine
+    plan.close()
+    ss.close()
