@@ -350,6 +350,16 @@ extern "C" int gams_gpu_sw(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, int32_t 
     uint64_t tot = 0;
     for (uint32_t f = 0; f < nf; ++f) {
         off[f] = tot;
+        {
+            // window.rs:98-110: the middle pair of the feature must be members of the ctg span --
+            // IntSpan::index of a non-member has no defined answer in the reference to mirror
+            const int64_t flen = (int64_t)feat_end[f] - feat_start[f] + 1, half = flen / 2;
+            const int64_t mid_l = half == 0 ? feat_start[f] : (int64_t)feat_start[f] + half - 1;
+            const int64_t mid_r = half == 0 ? feat_start[f] : (int64_t)feat_start[f] + half;
+            if (flen < 1 || mid_l < chr_start || mid_r > chr_end)
+                return gams_fail(h, GAMS_EINVAL,
+                                 "gpu_sw: feature " + std::to_string(f) + " is empty or has its middle outside the ctg");
+        }
         const SwGeom g = sw_geometry(chr_start, chr_end, feat_start[f], feat_end[f], size, max);
         tot += 1u + (uint64_t)g.n_l + (uint64_t)g.n_r;
     }

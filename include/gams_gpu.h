@@ -173,7 +173,10 @@ typedef struct {
     float gc_cv;
 } gams_sw_row_t;
 
-/* rows per feature = 1 + nL + nR (window.rs:29-41); writes at most `cap` rows
+/* Features are inclusive chromosome ranges whose middle lies inside the ctg (GAMS_EINVAL otherwise:
+ * center_resize takes parent.index(mid), window.rs:98-111, undefined for a non-member); size and
+ * resize >= 2.
+ * rows per feature = 1 + nL + nR (window.rs:29-41); writes at most `cap` rows
  * in the reference's order (feature order, then M, L1.., R1..). ctg i of `s`
  * spans chromosome coordinates [chr_start, chr_start+len-1]. */
 int gams_gpu_sw(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, int32_t chr_start,

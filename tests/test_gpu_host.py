@@ -398,3 +398,15 @@ def test_sw_multi_handles_equals_per_ctg(eng, s288c, n_handles):
     for x in engs[1:]:
         x.close()
     assert got == exp
+
+
+def test_sw_rejects_features_whose_middle_is_outside_the_ctg(eng, s288c):
+    """center_resize asks parent.index(mid) (window.rs:110-111): undefined for a non-member; reported instead"""
+    c = helpers.gen_ctgs("I", s288c["I"], piece=100000)[1]
+    ok = [("f:1", c["chr_start"], c["chr_start"]), ("f:2", c["chr_end"] - 30, c["chr_end"] + 10)]   # middle still inside
+    assert host.sw(eng, c, ok).count("\n") > 0
+    for s, e in ((c["chr_start"] - 500, c["chr_start"] + 10), (c["chr_end"] - 10, c["chr_end"] + 5000),
+                 (c["chr_end"] + 10**6, c["chr_end"] + 10**6 + 5), (500, 400)):
+        with pytest.raises(Exception) as ei:
+            host.sw(eng, c, [("f:x", s, e)])
+        assert "middle outside the ctg" in str(ei.value)
