@@ -433,6 +433,13 @@ extern "C" int gams_gpu_range_gc(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, in
         return gams_fail(h, GAMS_EINVAL, "gpu_range_gc: null argument");
     if (i >= s->n_ctg) return gams_fail(h, GAMS_EINVAL, "gpu_range_gc: ctg index out of range");
     if (s->len[i] == 0 || s->len[i] > 0x7fffffffu) return gams_fail(h, GAMS_EINVAL, "gpu_range_gc: ctg length out of range");
+    {
+        // utils.rs:151-156 slices seq[from-1..to): a range outside the ctg (or inverted) panics there
+        const int64_t chr_end = (int64_t)chr_start + s->len[i] - 1;
+        for (uint32_t k = 0; k < n; ++k)
+            if (range_start[k] < chr_start || range_end[k] > chr_end || range_end[k] < range_start[k])
+                return gams_fail(h, GAMS_EINVAL, "gpu_range_gc: range " + std::to_string(k) + " is not inside the ctg");
+    }
     GAMS_HIP(h, hipSetDevice(h->device));
     if (n == 0) return GAMS_OK;
     int rc = gams_seqset_gcindex(h, s);
