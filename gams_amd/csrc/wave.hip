@@ -856,13 +856,16 @@ int gams_wave_peaks(gams_gpu_t *h, gams_wave_plan_t *p, const gams_peak_t **peak
         if (worst > p->tile_cap) {
             // some tile signalled more windows than its slot holds: give every tile a slot of
             // tw records (the maximum possible) and run again
-            // (earlier runs still held by other ways are dropped with the old slots)
+            // (every way gets new slots, so every pass still held is run again: same inputs, same results)
             p->tile_cap_req = p->tw;
+            const uint32_t age = p->sel_age;
+            const uint32_t again = (uint32_t)std::min<uint64_t>(p->depth, p->run_idx);
             int rc = wave_sync_ways(h, p);
             if (rc == GAMS_OK) rc = wave_upload_geometry(h, p);
             if (rc == GAMS_OK) {
                 p->run_idx = 0;
-                rc = gams_wave_run(h, p);
+                for (uint32_t k = 0; k < again && rc == GAMS_OK; ++k) rc = gams_wave_run(h, p);
+                p->sel_age = age;
             }
             if (rc != GAMS_OK) return rc;
             continue;
