@@ -32,6 +32,9 @@ int gams_gpu_create(int device, gams_gpu_t **out) {
         return bail(e, "hipStreamCreate(compute)");
     if ((e = hipStreamCreateWithFlags(&h->copy, hipStreamNonBlocking)) != hipSuccess)
         return bail(e, "hipStreamCreate(copy)");
+    if ((e = hipStreamCreateWithFlags(&h->copy2, hipStreamNonBlocking)) != hipSuccess)
+        return bail(e, "hipStreamCreate(copy2)");
+    if ((e = hipEventCreateWithFlags(&h->copy2_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipStreamCreateWithFlags(&h->readback, hipStreamNonBlocking)) != hipSuccess)
         return bail(e, "hipStreamCreate(readback)");
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -55,6 +58,11 @@ void gams_gpu_destroy(gams_gpu_t *h) {
         (void)hipStreamSynchronize(h->copy);
         (void)hipStreamDestroy(h->copy);
     }
+    if (h->copy2) {
+        (void)hipStreamSynchronize(h->copy2);
+        (void)hipStreamDestroy(h->copy2);
+    }
+    if (h->copy2_ev) (void)hipEventDestroy(h->copy2_ev);
     if (h->readback) {
         (void)hipStreamSynchronize(h->readback);
         (void)hipStreamDestroy(h->readback);
@@ -95,6 +103,7 @@ int gams_gpu_sync(gams_gpu_t *h) {
     if (!h) return GAMS_EINVAL;
     GAMS_HIP(h, hipSetDevice(h->device));
     GAMS_HIP(h, hipStreamSynchronize(h->copy));
+    GAMS_HIP(h, hipStreamSynchronize(h->copy2));
     GAMS_HIP(h, hipStreamSynchronize(h->compute));
     for (int k = 0; k < gams_gpu::kMaxWays - 1; ++k)
         if (h->aux[k]) GAMS_HIP(h, hipStreamSynchronize(h->aux[k]));
@@ -251,7 +260,12 @@ int gams_seqset_upload_all(gams_gpu_t *h, gams_seqset_t *s, const uint8_t *const
     const unsigned T = (unsigned)std::min<uint64_t>(gams_gpu::kStageSlots, std::max<uint64_t>(n_win, 1));
     std::atomic<int> failed{0};
     std::string err[gams_gpu::kStageSlots];
+    // odd slots go through a second stream (a second DMA engine); it starts behind whatever the
+    // first one already holds for this seqset (the memset of gams_seqset_create, earlier uploads)
+    GAMS_HIP(h, hipEventRecord(s->uploaded, h->copy));
+    GAMS_HIP(h, hipStreamWaitEvent(h->copy2, s->uploaded, 0));
     auto work = [&](unsigned t) {
+        hipStream_t cs = (t & 1u) ? h->copy2 : h->copy;
         hipError_t e = hipSetDevice(h->device);
         for (uint64_t w = t; w < n_win && e == hipSuccess && !failed.load(); w += T) {
             const uint64_t lo = w * W, hi = std::min(end, lo + W);
@@ -273,8 +287,8 @@ int gams_seqset_upload_all(gams_gpu_t *h, gams_seqset_t *s, const uint8_t *const
                 }
             }
             if (hi > filled) std::memset(dst + (filled - lo), 0, hi - filled);
-            e = hipMemcpyAsync(s->d_seq + lo, dst, hi - lo, hipMemcpyHostToDevice, h->copy);
-            if (e == hipSuccess) e = hipEventRecord(h->stage_free[t], h->copy);
+            e = hipMemcpyAsync(s->d_seq + lo, dst, hi - lo, hipMemcpyHostToDevice, cs);
+            if (e == hipSuccess) e = hipEventRecord(h->stage_free[t], cs);
         }
         if (e != hipSuccess) {
             err[t] = hipGetErrorString(e);
@@ -289,6 +303,8 @@ int gams_seqset_upload_all(gams_gpu_t *h, gams_seqset_t *s, const uint8_t *const
         for (auto &m : err)
             if (!m.empty()) return gams_fail(h, GAMS_EHIP, "seqset_upload_all: " + m);
     }
+    GAMS_HIP(h, hipEventRecord(h->copy2_ev, h->copy2));
+    GAMS_HIP(h, hipStreamWaitEvent(h->copy, h->copy2_ev, 0));
     GAMS_HIP(h, hipEventRecord(s->uploaded, h->copy));
     s->dirty = true;
     ++s->upload_gen;
@@ -302,6 +318,7 @@ void gams_seqset_destroy(gams_gpu_t *h, gams_seqset_t *s) {
         (void)hipStreamSynchronize(h->compute);
     }
     if (h) (void)hipStreamSynchronize(h->copy);
+    if (h) (void)hipStreamSynchronize(h->copy2);
     gams_seqset_gcindex_free(s);
     if (s->uploaded) (void)hipEventDestroy(s->uploaded);
     gams_pool_free(h, false, s->d_seq, s->cap);
