@@ -63,3 +63,9 @@ print("last 16 workgroups to finish: entry us, end us, phase cycles")
 for w in last:
     print(f"   entry {entry[w]:5.2f}  end {end[w]:5.2f}  phases {dur[w].tolist()}")
 print("end-time percentiles us", np.percentile(end, [50, 90, 95, 99, 100]).round(2))
+# is the workgroup -> XCD map round robin?  (stamps rows are indexed by blockIdx.x)
+full = buf.reshape(-1, 16)
+ids = np.flatnonzero(full[:, 10] != 0)
+x = (full[ids, 11] >> np.uint64(32)).astype(int)
+print("blockIdx % 8 == XCC_ID for", int((ids % 8 == x).sum()), "of", ids.size, "workgroups;",
+      "distinct (blockIdx % 8 -> xcc) pairs:", sorted(set(zip((ids % 8).tolist(), x.tolist())))[:16])
