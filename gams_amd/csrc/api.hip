@@ -30,10 +30,15 @@ int gams_gpu_create(int device, gams_gpu_t **out) {
     snprintf(h->arch, sizeof h->arch, "%s", prop.gcnArchName);
     if ((e = hipStreamCreateWithFlags(&h->compute, hipStreamNonBlocking)) != hipSuccess)
         return bail(e, "hipStreamCreate(compute)");
+    // The streams a plan of depth D runs on are created first and together: HIP hands streams to
+    // its hardware queues (GPU_MAX_HW_QUEUES, 4 by default, one per CP pipe) in creation order, and
+    // streams that end up on queues of the same pipe overlap their kernels badly (tools/queue_map.hip:
+    // 9.8 us per launch for four consecutive streams, 14-17 us for {0,2,4,6} on 8 queues).
+    for (int k = 0; k < gams_gpu::kMaxWays - 1; ++k)
+        if ((e = hipStreamCreateWithFlags(&h->aux[k], hipStreamNonBlocking)) != hipSuccess)
+            return bail(e, "hipStreamCreate(aux)");
     if ((e = hipStreamCreateWithFlags(&h->copy, hipStreamNonBlocking)) != hipSuccess)
         return bail(e, "hipStreamCreate(copy)");
-    if ((e = hipStreamCreateWithFlags(&h->copy2, hipStreamNonBlocking)) != hipSuccess)
-        return bail(e, "hipStreamCreate(copy2)");
     if ((e = hipEventCreateWithFlags(&h->copy2_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipStreamCreateWithFlags(&h->readback, hipStreamNonBlocking)) != hipSuccess)
         return bail(e, "hipStreamCreate(readback)");
@@ -57,10 +62,6 @@ void gams_gpu_destroy(gams_gpu_t *h) {
     if (h->copy) {
         (void)hipStreamSynchronize(h->copy);
         (void)hipStreamDestroy(h->copy);
-    }
-    if (h->copy2) {
-        (void)hipStreamSynchronize(h->copy2);
-        (void)hipStreamDestroy(h->copy2);
     }
     if (h->copy2_ev) (void)hipEventDestroy(h->copy2_ev);
     if (h->readback) {
@@ -103,7 +104,6 @@ int gams_gpu_sync(gams_gpu_t *h) {
     if (!h) return GAMS_EINVAL;
     GAMS_HIP(h, hipSetDevice(h->device));
     GAMS_HIP(h, hipStreamSynchronize(h->copy));
-    GAMS_HIP(h, hipStreamSynchronize(h->copy2));
     GAMS_HIP(h, hipStreamSynchronize(h->compute));
     for (int k = 0; k < gams_gpu::kMaxWays - 1; ++k)
         if (h->aux[k]) GAMS_HIP(h, hipStreamSynchronize(h->aux[k]));
@@ -260,12 +260,15 @@ int gams_seqset_upload_all(gams_gpu_t *h, gams_seqset_t *s, const uint8_t *const
     const unsigned T = (unsigned)std::min<uint64_t>(gams_gpu::kStageSlots, std::max<uint64_t>(n_win, 1));
     std::atomic<int> failed{0};
     std::string err[gams_gpu::kStageSlots];
-    // odd slots go through a second stream (a second DMA engine); it starts behind whatever the
-    // first one already holds for this seqset (the memset of gams_seqset_create, earlier uploads)
+    // odd slots go through a second stream (a second DMA engine) -- the readback stream, idle during
+    // an upload; a stream of its own would cost one more of the few hardware queues HIP maps
+    // streams onto (GPU_MAX_HW_QUEUES, 4 by default).  It starts behind whatever `copy` already
+    // holds for this seqset (the memset of gams_seqset_create, earlier uploads).
+    hipStream_t second = h->readback;
     GAMS_HIP(h, hipEventRecord(s->uploaded, h->copy));
-    GAMS_HIP(h, hipStreamWaitEvent(h->copy2, s->uploaded, 0));
+    GAMS_HIP(h, hipStreamWaitEvent(second, s->uploaded, 0));
     auto work = [&](unsigned t) {
-        hipStream_t cs = (t & 1u) ? h->copy2 : h->copy;
+        hipStream_t cs = (t & 1u) ? second : h->copy;
         hipError_t e = hipSetDevice(h->device);
         for (uint64_t w = t; w < n_win && e == hipSuccess && !failed.load(); w += T) {
             const uint64_t lo = w * W, hi = std::min(end, lo + W);
@@ -303,7 +306,7 @@ int gams_seqset_upload_all(gams_gpu_t *h, gams_seqset_t *s, const uint8_t *const
         for (auto &m : err)
             if (!m.empty()) return gams_fail(h, GAMS_EHIP, "seqset_upload_all: " + m);
     }
-    GAMS_HIP(h, hipEventRecord(h->copy2_ev, h->copy2));
+    GAMS_HIP(h, hipEventRecord(h->copy2_ev, second));
     GAMS_HIP(h, hipStreamWaitEvent(h->copy, h->copy2_ev, 0));
     GAMS_HIP(h, hipEventRecord(s->uploaded, h->copy));
     s->dirty = true;
@@ -318,7 +321,7 @@ void gams_seqset_destroy(gams_gpu_t *h, gams_seqset_t *s) {
         (void)hipStreamSynchronize(h->compute);
     }
     if (h) (void)hipStreamSynchronize(h->copy);
-    if (h) (void)hipStreamSynchronize(h->copy2);
+    if (h) (void)hipStreamSynchronize(h->readback);
     gams_seqset_gcindex_free(s);
     if (s->uploaded) (void)hipEventDestroy(s->uploaded);
     gams_pool_free(h, false, s->d_seq, s->cap);

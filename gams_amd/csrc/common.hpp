@@ -16,8 +16,7 @@ struct gams_gpu {
     int device = 0;
     hipStream_t compute = nullptr;  // every kernel of the library runs here
     hipStream_t copy = nullptr;     // H2D staging of seq: bytes
-    hipStream_t copy2 = nullptr;    // second DMA queue of gams_seqset_upload_all (odd staging slots)
-    hipEvent_t copy2_ev = nullptr;
+    hipEvent_t copy2_ev = nullptr;  // gams_seqset_upload_all: joins the second DMA queue (the readback stream) into `copy`
     hipStream_t readback = nullptr; // packing + D2H of a finished run's results (waits on that run only)
     // a wave plan of depth D rotates its runs over `compute` and aux[0..D-2] (gams_wave_plan_set_depth)
     static constexpr int kMaxWays = 4;
