@@ -266,6 +266,14 @@ def merge_windows(windows, chr_start, size, step, coverage):
     return cmin, cmax, ing.astype(bool)
 
 
+def ctg_json_roundtrip(json_text):
+    """parse a `ctg:` JSON record (redis.rs:132-135) and write it back the way serde_json does (:127-130)"""
+    L = load()
+    L.gams_host_ctg_json_roundtrip.restype = C.c_void_p
+    L.gams_host_ctg_json_roundtrip.argtypes = [C.c_char_p]
+    return _take(L.gams_host_ctg_json_roundtrip(json_text.encode()))
+
+
 def header(command):
     """the header line `gams wave` / `gams sw` print before the rows"""
     return _take(load().gams_host_header(0 if command == "wave" else 1))

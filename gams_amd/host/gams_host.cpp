@@ -952,6 +952,65 @@ std::string json_escape(const std::string &v) {
 }
 }  // namespace
 
+std::string ctg_json(const Ctg &c) {
+    return "{\"id\":\"" + json_escape(c.id) + "\",\"range\":\"" + json_escape(c.range) + "\",\"chr_id\":\"" +
+           json_escape(c.chr_id) + "\",\"chr_start\":" + std::to_string(c.chr_start) + ",\"chr_end\":" +
+           std::to_string(c.chr_end) + ",\"chr_strand\":\"" + json_escape(c.chr_strand) + "\",\"length\":" +
+           std::to_string(c.length) + "}";
+}
+
+Ctg ctg_from_json(const std::string &json) {
+    // flat object of strings and integers, any field order, whitespace tolerated
+    Ctg c;
+    size_t pos = 0;
+    auto skip = [&] {
+        while (pos < json.size() && (json[pos] == ' ' || json[pos] == '\n' || json[pos] == '\t' || json[pos] == '\r')) ++pos;
+    };
+    auto str = [&]() {
+        std::string v;
+        if (pos >= json.size() || json[pos] != '"') throw Error(GAMS_EINVAL, "ctg_from_json: expected a string");
+        for (++pos; pos < json.size() && json[pos] != '"'; ++pos) {
+            if (json[pos] == '\\' && pos + 1 < json.size()) ++pos;
+            v += json[pos];
+        }
+        if (pos >= json.size()) throw Error(GAMS_EINVAL, "ctg_from_json: unterminated string");
+        ++pos;
+        return v;
+    };
+    skip();
+    if (pos >= json.size() || json[pos] != '{') throw Error(GAMS_EINVAL, "ctg_from_json: not an object");
+    ++pos;
+    for (;;) {
+        skip();
+        if (pos < json.size() && json[pos] == '}') break;
+        const std::string key = str();
+        skip();
+        if (pos >= json.size() || json[pos] != ':') throw Error(GAMS_EINVAL, "ctg_from_json: expected ':'");
+        ++pos;
+        skip();
+        if (pos < json.size() && json[pos] == '"') {
+            const std::string v = str();
+            if (key == "id") c.id = v;
+            else if (key == "range") c.range = v;
+            else if (key == "chr_id") c.chr_id = v;
+            else if (key == "chr_strand") c.chr_strand = v;
+        } else {
+            size_t e = pos;
+            while (e < json.size() && (json[e] == '-' || (json[e] >= '0' && json[e] <= '9'))) ++e;
+            if (e == pos) throw Error(GAMS_EINVAL, "ctg_from_json: expected a number");
+            const int32_t v = (int32_t)std::stol(json.substr(pos, e - pos));
+            pos = e;
+            if (key == "chr_start") c.chr_start = v;
+            else if (key == "chr_end") c.chr_end = v;
+            else if (key == "length") c.length = v;
+        }
+        skip();
+        if (pos < json.size() && json[pos] == ',') ++pos;
+    }
+    if (c.id.empty() || c.chr_id.empty()) throw Error(GAMS_EINVAL, "ctg_from_json: id / chr_id missing");
+    return c;
+}
+
 std::string tsv_ctgs(const std::vector<Ctg> &ctgs) {
     std::string out = "id\trange\tchr_id\tchr_start\tchr_end\tchr_strand\tlength\n";   // data.rs:5-14
     for (const Ctg &c : ctgs)

@@ -168,6 +168,11 @@ std::vector<Peak> peak_records(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq
 struct Record {
     std::string key, json;
 };
+// serde_json text of a Ctg as `gen` stores it under its id (redis.rs:127-130, data.rs:5-14) and the
+// reverse (redis.rs:132-135); field order and number formats as serde_json writes them.
+std::string ctg_json(const Ctg &c);
+Ctg ctg_from_json(const std::string &json);
+
 // header lines the commands print in front of the per-ctg rows (wave.rs:263-266, sw.rs:204-216)
 inline const char *wave_header() { return "#range\tgc_content\tsignal\n"; }
 inline const char *sw_header() { return "id\trange\ttype\tdistance\tgc_content\tgc_mean\tgc_stddev\tgc_cv\trg_count\n"; }

@@ -372,6 +372,11 @@ void gams_host_merge_windows(const uint32_t *w, uint64_t n, int32_t chr_start, i
     gams::merge_windows(w, (size_t)n, chr_start, size, step, coverage, cmin, cmax, in_graph);
 }
 
+// serde_json round trip of a ctg: record (redis.rs:127-135); returns the JSON re-serialised from the parse
+char *gams_host_ctg_json_roundtrip(const char *json) {
+    return guarded([&] { return gams::ctg_json(gams::ctg_from_json(json)); });
+}
+
 // formatting helpers exposed for CPU-only tests
 char *gams_host_fmt_f32(float v) { return dup(gams::fmt_f32(v)); }
 char *gams_host_range_roundtrip(const char *s) {

@@ -120,3 +120,21 @@ def test_merge_ints_against_the_pairwise_rule():
             members = [k for k in range(w.size) if roots[k] == roots[i]]
             assert cmin[i] == min(s[k] for k in members) and cmax[i] == max(e[k] for k in members), (it, i)
         assert np.array_equal(ing, edge), it
+
+
+def test_ctg_json_record_roundtrip():
+    """the `ctg:{chr}:{sn}` value `gen` stores (serde_json of data.rs:5-14, redis.rs:127-135): field order and
+    number formats of serde_json; the parser takes any field order and whitespace"""
+    import helpers
+    import json
+
+    for row in helpers.read_lines("ctg.tsv")[1:]:
+        f = row.split("\t")
+        rec = dict(id=f[0], range=f[1], chr_id=f[2], chr_start=int(f[3]), chr_end=int(f[4]), chr_strand=f[5],
+                   length=int(f[6]))
+        compact = json.dumps(rec, separators=(",", ":"))           # what serde_json::to_string writes
+        assert host.ctg_json_roundtrip(compact) == compact
+        shuffled = json.dumps(dict(reversed(list(rec.items()))), indent=2)
+        assert host.ctg_json_roundtrip(shuffled) == compact
+    with pytest.raises(Exception):
+        host.ctg_json_roundtrip('{"range":"I:1-5"}')
