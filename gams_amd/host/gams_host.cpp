@@ -768,23 +768,49 @@ std::vector<std::string> Locator::find(const std::vector<Range> &rgs) {
 }
 
 std::string Locator::locate(const std::vector<std::string> &rgs, bool is_count) {
+    // range strings are parsed and rows are formatted on several host threads (contiguous runs of
+    // lines, concatenated in order); the lookups in between are one device call each
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>({8, std::thread::hardware_concurrency(), rgs.size() / 20000}));
+    auto cut = [&](size_t n, unsigned t) { return n * t / T; };
+    std::vector<std::vector<Range>> vpart(T);
+    std::vector<std::vector<size_t>> spart(T);
+    run_shares(T, [&](uint32_t t) {
+        for (size_t i = cut(rgs.size(), t); i < cut(rgs.size(), t + 1); ++i) {   // locate.rs:111-116
+            Range r = Range::from_str(rgs[i]);
+            if (!r.valid) continue;
+            r.strand.clear();
+            vpart[t].push_back(std::move(r));
+            spart[t].push_back(i);
+        }
+    });
     std::vector<Range> valid;
     std::vector<size_t> src;
-    for (size_t i = 0; i < rgs.size(); ++i) {                           // locate.rs:111-116
-        Range r = Range::from_str(rgs[i]);
-        if (!r.valid) continue;
-        r.strand.clear();
-        valid.push_back(r);
-        src.push_back(i);
+    for (unsigned t = 0; t < T; ++t) {
+        valid.insert(valid.end(), std::make_move_iterator(vpart[t].begin()), std::make_move_iterator(vpart[t].end()));
+        src.insert(src.end(), spart[t].begin(), spart[t].end());
     }
     std::vector<std::string> ctg_ids = find(valid);
-    std::string out;
-    if (!is_count) {
-        for (size_t k = 0; k < valid.size(); ++k) {
-            if (ctg_ids[k].empty()) continue;                           // locate.rs:120-122
-            out += rgs[src[k]] + "\t" + ctg_ids[k] + "\n";             // locate.rs:139
-        }
+    std::vector<std::string> opart(T);
+    auto join = [&] {
+        std::string out;
+        size_t bytes = 0;
+        for (auto &x : opart) bytes += x.size();
+        out.reserve(bytes);
+        for (auto &x : opart) out += x;
         return out;
+    };
+    if (!is_count) {
+        run_shares(T, [&](uint32_t t) {
+            std::string &o = opart[t];
+            for (size_t k = cut(valid.size(), t); k < cut(valid.size(), t + 1); ++k) {
+                if (ctg_ids[k].empty()) continue;                       // locate.rs:120-122
+                o += rgs[src[k]];
+                o += '\t';
+                o += ctg_ids[k];                                        // locate.rs:139
+                o += '\n';
+            }
+        });
+        return join();
     }
     if (!rg_ix_) throw Error(GAMS_ESTATE, "locate --count: no rg index loaded");
     std::vector<uint32_t> grp, qs, qe;
@@ -800,9 +826,16 @@ std::string Locator::locate(const std::vector<std::string> &rgs, bool is_count) 
     }
     std::vector<int32_t> cnt(who.size() ? who.size() : 1);
     check(h_, gams_gpu_count(h_, rg_ix_, grp.data(), qs.data(), qe.data(), who.size(), cnt.data()));
-    for (size_t j = 0; j < who.size(); ++j)
-        out += rgs[src[who[j]]] + "\t" + std::to_string(cnt[j]) + "\n";  // locate.rs:137
-    return out;
+    run_shares(T, [&](uint32_t t) {
+        std::string &o = opart[t];
+        for (size_t j = cut(who.size(), t); j < cut(who.size(), t + 1); ++j) {
+            o += rgs[src[who[j]]];
+            o += '\t';
+            o += std::to_string(cnt[j]);                                // locate.rs:137
+            o += '\n';
+        }
+    });
+    return join();
 }
 
 std::string Locator::locate_seq(const std::vector<std::string> &rgs,
@@ -1213,45 +1246,79 @@ std::string anno(gams_gpu_t *h, const std::map<std::string, Runlist> &sets, cons
         ~Guard() { gams_spans_destroy(h, sp); }
     } guard{h, sp};
 
-    std::vector<size_t> keep;  // lines that produce a row
-    std::vector<uint32_t> grp;
-    std::vector<int32_t> cl, ch, qs, qe;
-    for (size_t i = 0; i < lines.size(); ++i) {                        // anno.rs:97
-        if (header && i == 0) continue;
-        std::vector<std::string> parts = split_tab(lines[i]);
-        if (idx_id == 0 || idx_range == 0 || idx_id > parts.size() || idx_range > parts.size())
-            throw Error(GAMS_EINVAL, "anno: field index out of range (the reference panics, anno.rs:115)");
-        std::string ctg_id;
-        if (!extract_ctg_id(parts[idx_id - 1], ctg_id)) continue;       // anno.rs:116-119
-        Range r = Range::from_str(parts[idx_range - 1]);
-        if (!r.valid) continue;                                         // anno.rs:123-125
-        auto gi = group_of.find(r.chr);
-        uint32_t gq = UINT32_MAX;
-        int32_t c0 = 0, c1 = 0;
-        if (gi != group_of.end()) {                                     // anno.rs:129
-            auto ci = ctg_of.find(ctg_id);
-            if (ci == ctg_of.end())
-                throw Error(GAMS_EINVAL, "anno: unknown " + ctg_id + " (the reference panics, redis.rs:133-134)");
-            gq = gi->second;
-            c0 = ci->second->chr_start;
-            c1 = ci->second->chr_end;
+    // parse the lines on several threads (each a contiguous run, results concatenated in order),
+    // one device call, then format the rows the same way
+    struct Part {
+        std::vector<size_t> keep;  // lines that produce a row
+        std::vector<uint32_t> grp;
+        std::vector<int32_t> cl, ch, qs, qe;
+        std::string out;
+    };
+    const size_t first = header ? 1 : 0;
+    const size_t n_lines = lines.size() > first ? lines.size() - first : 0;
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>({8, std::thread::hardware_concurrency(), n_lines / 20000}));
+    std::vector<Part> part(T);
+    run_shares(T, [&](uint32_t t) {
+        Part &P = part[t];
+        const size_t b0 = first + n_lines * t / T, b1 = first + n_lines * (t + 1) / T;
+        for (size_t i = b0; i < b1; ++i) {                             // anno.rs:97
+            std::vector<std::string> parts = split_tab(lines[i]);
+            if (idx_id == 0 || idx_range == 0 || idx_id > parts.size() || idx_range > parts.size())
+                throw Error(GAMS_EINVAL, "anno: field index out of range (the reference panics, anno.rs:115)");
+            std::string ctg_id;
+            if (!extract_ctg_id(parts[idx_id - 1], ctg_id)) continue;   // anno.rs:116-119
+            Range r = Range::from_str(parts[idx_range - 1]);
+            if (!r.valid) continue;                                     // anno.rs:123-125
+            auto gi = group_of.find(r.chr);
+            uint32_t gq = UINT32_MAX;
+            int32_t c0 = 0, c1 = 0;
+            if (gi != group_of.end()) {                                 // anno.rs:129
+                auto ci = ctg_of.find(ctg_id);
+                if (ci == ctg_of.end())
+                    throw Error(GAMS_EINVAL, "anno: unknown " + ctg_id + " (the reference panics, redis.rs:133-134)");
+                gq = gi->second;
+                c0 = ci->second->chr_start;
+                c1 = ci->second->chr_end;
+            }
+            P.keep.push_back(i);
+            P.grp.push_back(gq);
+            P.cl.push_back(c0);
+            P.ch.push_back(c1);
+            P.qs.push_back(r.start);
+            P.qe.push_back(r.end);
         }
-        keep.push_back(i);
-        grp.push_back(gq);
-        cl.push_back(c0);
-        ch.push_back(c1);
-        qs.push_back(r.start);
-        qe.push_back(r.end);
+    });
+    std::vector<size_t> base(T + 1, 0);
+    for (unsigned t = 0; t < T; ++t) base[t + 1] = base[t] + part[t].keep.size();
+    const size_t nk = base[T];
+    std::vector<uint32_t> grp(nk ? nk : 1);
+    std::vector<int32_t> cl(nk ? nk : 1), ch(nk ? nk : 1), qs(nk ? nk : 1), qe(nk ? nk : 1);
+    for (unsigned t = 0; t < T; ++t) {
+        std::copy(part[t].grp.begin(), part[t].grp.end(), grp.begin() + base[t]);
+        std::copy(part[t].cl.begin(), part[t].cl.end(), cl.begin() + base[t]);
+        std::copy(part[t].ch.begin(), part[t].ch.end(), ch.begin() + base[t]);
+        std::copy(part[t].qs.begin(), part[t].qs.end(), qs.begin() + base[t]);
+        std::copy(part[t].qe.begin(), part[t].qe.end(), qe.begin() + base[t]);
     }
-    std::vector<float> prop(keep.size() ? keep.size() : 1);
-    check(h, gams_gpu_cover(h, sp, grp.data(), cl.data(), ch.data(), qs.data(), qe.data(), keep.size(), prop.data()));
+    std::vector<float> prop(nk ? nk : 1);
+    check(h, gams_gpu_cover(h, sp, grp.data(), cl.data(), ch.data(), qs.data(), qe.data(), nk, prop.data()));
+    run_shares(T, [&](uint32_t t) {
+        Part &P = part[t];
+        char buf[64];
+        size_t bytes = 0;
+        for (size_t i : P.keep) bytes += lines[i].size() + 9;
+        P.out.reserve(bytes);
+        for (size_t k = 0; k < P.keep.size(); ++k) {
+            snprintf(buf, sizeof buf, "%.4f", (double)prop[base[t] + k]);   // anno.rs:140 {:.4}
+            P.out += lines[P.keep[k]];
+            P.out += '\t';
+            P.out += buf;
+            P.out += '\n';
+        }
+    });
     std::string out;
     if (header && !lines.empty()) out += lines[0] + "\t" + prefix + "Prop\n";  // anno.rs:108
-    char buf[64];
-    for (size_t k = 0; k < keep.size(); ++k) {
-        snprintf(buf, sizeof buf, "%.4f", (double)prop[k]);             // anno.rs:140 {:.4}
-        out += lines[keep[k]] + "\t" + buf + "\n";
-    }
+    for (unsigned t = 0; t < T; ++t) out += part[t].out;
     return out;
 }
 
