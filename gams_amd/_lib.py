@@ -63,6 +63,7 @@ PROTOTYPES = {
     "gams_wave_dense": (C.c_int, [_VP, _VP, C.c_uint32, _VP, _VP]),
     "gams_wave_plan_set_tile": (C.c_int, [_VP, _VP, C.c_uint32]),
     "gams_wave_exact_count": (C.c_int, [_VP, _VP, C.POINTER(C.c_uint64)]),
+    "gams_wave_plan_set_guard": (C.c_int, [_VP, _VP, C.c_float, C.c_int]),
     "gams_wave_plan_set_stamps": (C.c_int, [_VP, _VP, C.c_int]),
     "gams_wave_stamps": (C.c_int, [_VP, _VP, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "gams_wave_stamps_raw": (C.c_int, [_VP, _VP, _VP, C.c_uint64]),
@@ -84,10 +85,13 @@ PROTOTYPES = {
 _lib = None
 
 
-def bind(path):
-    """dlopen one build of the library and bind every prototype of include/gams_gpu.h."""
+def bind(path, strict=True):
+    """dlopen one build of the library and bind every prototype of include/gams_gpu.h.
+    strict=False (tools/ab.py comparing against an older build) skips entry points it lacks."""
     lib = C.CDLL(path)
     for name, (res, args) in PROTOTYPES.items():
+        if not strict and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args

@@ -108,6 +108,9 @@ struct gams_wave_plan {
     bool pipelined = false;       // gams_wave_plan_set_pipelined: an event per run; readers wait on it
     bool attr_set = false;        // dynamic-LDS attribute applied for the current geometry
     float g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+    float sq[6] = {0, 0, 0, 0, 0, 0};   // aA, aB, gA0, gA1, gB0, gB1 (wave_squared_band)
+    float guard_safety = 1.5f;          // gams_wave_plan_set_guard
+    bool guard_exact = false;           // every window through the exact path
 };
 static void wave_launcher_stop(gams_wave_plan_t *p);
 
@@ -132,11 +135,13 @@ size_t wave_lds_bytes(uint32_t max_chunks, uint32_t max_win, bool wide, bool k16
 
 // Guard band of the integer decision, in units of D = |n*k - S1| (see DESIGN.md
 // "z-score guard band" for the derivation).  u = 2^-24.
-void wave_guard_band(const gams_wave_params_t &p, float g[4]) {
+void wave_guard_band(const gams_wave_params_t &p, double safety, bool all_exact, float g[4]) {
     const double u = std::ldexp(1.0, -24);
     const double n = (double)p.lag, sz = (double)p.size;
     const double thr = std::fabs((double)p.threshold);
-    if (!(std::isfinite(p.threshold)) || p.threshold < 0.0f || p.lag < 2) {
+    // The squared-domain decision divides by thr*sqrt(n/(n-1)): thresholds outside [1e-6, 1e6]
+    // (and non-finite or negative ones) are not worth a fast path, every window is exact.
+    if (all_exact || !(std::isfinite(p.threshold)) || p.threshold < 1e-6f || p.threshold > 1e6f || p.lag < 2) {
         g[0] = INFINITY;  // every window takes the exact path
         g[1] = g[2] = g[3] = 0.0f;
         return;
@@ -144,18 +149,46 @@ void wave_guard_band(const gams_wave_params_t &p, float g[4]) {
     const double gam = 1.01 * (n + 1.0) * u / (1.0 - (n + 1.0) * u);  // f32 sequential mean
     const double kap = std::sqrt(n / (n - 1.0));
     const double eta = 1.01 * ((n + 3.0) / 2.0 + 2.0) * u;              // sq sum, /, sqrt, *thr
-    const double safety = 1.5;
     g[1] = (float)(safety * (gam + 2.0 * u + thr * kap * gam * (1.0 + eta)));
     g[2] = (float)(safety * (eta + 8.0 * u));
     g[3] = (float)(safety * 3.0 * u);
     g[0] = (float)(safety * (2.0 * thr * kap * u * n * sz) + 1e-3);
 }
 
-size_t wave_fast_lds_bytes(uint32_t max_chunks, uint32_t tw, uint32_t lag, bool dense) {
+// The same band for z_decide (wave_kernels.hpp): with g = g2 + g3, c = g0 + g1*S1 and
+// sb = thr*sqrt(n/(n-1)),   A = D*(1-g)/((1+g) sb) - c/((1+g) sb),   B = D*(1+g)/((1-g) sb) + c/((1-g) sb).
+// The kernel's own roundings (one fma for c, one for A or B, 2u on V) are covered by rounding the
+// multiplier of A down and everything else up by a few u here, so that a decided window is
+// decided under the exact-arithmetic band above: A_f^2 > V_f implies A^2 > V, B_f^2 < V_f implies B^2 < V.
+void wave_squared_band(const gams_wave_params_t &p, const float g[4], float sq[6]) {
+    for (int i = 0; i < 6; ++i) sq[i] = 0.0f;
+    if (!(g[0] < INFINITY)) return;
+    const double u = std::ldexp(1.0, -24);
+    const double n = (double)p.lag;
+    const double sb = std::fabs((double)p.threshold) * std::sqrt(n / (n - 1.0));
+    const double gg = (double)g[2] + (double)g[3];
+    const double lo = 1.0 - 5.0 * u, hi = 1.0 + 7.0 * u;
+    sq[0] = (float)((1.0 - gg) / ((1.0 + gg) * sb) * lo);   // aA
+    sq[1] = (float)((1.0 + gg) / ((1.0 - gg) * sb) * hi);   // aB
+    sq[2] = (float)((double)g[0] / ((1.0 + gg) * sb) * hi); // gA0
+    sq[3] = (float)((double)g[1] / ((1.0 + gg) * sb) * hi); // gA1
+    sq[4] = (float)((double)g[0] / ((1.0 - gg) * sb) * hi); // gB0
+    sq[5] = (float)((double)g[1] / ((1.0 - gg) * sb) * hi); // gB1
+}
+
+// W of the baked instantiations of wave_fast_kernel (parameters in the instruction stream)
+bool wave_is_baked(const gams_wave_params_t &q, int w) {
+    const bool headline = q.size == 100 && q.step == 10 && q.lag == 100;   // every BASELINE step-10 config
+    const bool step1 = q.size == 100 && q.step == 1 && q.lag == 100;       // BASELINE configs[3] (GRCh38, step 1)
+    return (headline && (w == 12 || w == 8 || w == 4)) || (step1 && (w == 20 || w == 12));
+}
+
+size_t wave_fast_lds_bytes(uint32_t max_chunks, uint32_t w, uint32_t lag, bool dense) {
     size_t b = (size_t)((((max_chunks + 8u) >> 1) + 16u + 3u) & ~3u) * 4;   // BM: 16 mask bits per chunk + pad
     b += 16 * 4;                                         // scratch
-    b += (tw + lag + 1u + 31u) & ~15u;                   // K
-    if (dense) b += (tw + 15u) & ~15u;                   // SG
+    b += (256u * w + lag + 1u + 31u) & ~15u;             // K (threads past the tile's end still read their slots)
+    b += 272 * 8;                                        // PS: block sums of the baked kernels
+    if (dense) b += (256u * w + 15u) & ~15u;             // SG
     return (b + 15) & ~(size_t)15;
 }
 
@@ -208,13 +241,14 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
         }
         if (pick) {
             p->fast_w = pick;
-            p->tw = 256u * pick;
+            // baked kernels: the tile's windows plus the lag+1 in front fill 256*W slots exactly
+            p->tw = wave_is_baked(q, pick) ? 256u * pick - q.lag - 1u : 256u * pick;
             p->max_win = p->tw + q.lag + 1;
             // rounded up to whole 256-chunk rows: the baked kernels store every row they load
             p->max_chunks = ((uint32_t)((halo_bytes + (uint64_t)p->tw * q.step + 15) / 16) + 1 + 255u) & ~255u;
             p->k16 = false;
             p->wide = false;
-            p->lds_bytes = wave_fast_lds_bytes(p->max_chunks, p->tw, q.lag, (p->flags & GAMS_WAVE_DENSE) != 0);
+            p->lds_bytes = wave_fast_lds_bytes(p->max_chunks, (uint32_t)pick, q.lag, (p->flags & GAMS_WAVE_DENSE) != 0);
             wave_fill_tiles(p);
             return GAMS_OK;
         }
@@ -254,6 +288,16 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
     if (p->lds_bytes > 160 * 1024) return go_direct();
     wave_fill_tiles(p);
     return GAMS_OK;
+}
+
+void wave_set_band(gams_wave_plan_t *p) {
+    float g[4];
+    wave_guard_band(p->prm, (double)p->guard_safety, p->guard_exact, g);
+    p->g0 = g[0];
+    p->g1 = g[1];
+    p->g2 = g[2];
+    p->g3 = g[3];
+    wave_squared_band(p->prm, g, p->sq);
 }
 
 inline size_t wave_align256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -409,14 +453,7 @@ int gams_wave_plan_create(gams_gpu_t *h, gams_seqset_t *s, const gams_wave_param
         delete p;
         return rc;
     }
-    {
-        float g[4];
-        wave_guard_band(p->prm, g);
-        p->g0 = g[0];
-        p->g1 = g[1];
-        p->g2 = g[2];
-        p->g3 = g[3];
-    }
+    wave_set_band(p);
     auto fail = [&](int code) {
         gams_wave_plan_destroy(h, p);
         return code;
@@ -499,7 +536,21 @@ int gams_wave_plan_set_tile(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tile_wi
     p->ran = false;
     (void)hipFree(p->d_stamps);
     p->d_stamps = nullptr;
-    return wave_upload_geometry(h, p);
+    rc = wave_upload_geometry(h, p);
+    // a requested tile can move the plan from the tiled to the untiled kernels (prefix arrays beyond
+    // the LDS), which need the dense rows
+    if (rc == GAMS_OK) rc = wave_alloc_ways(h, p);
+    return rc;
+}
+
+int gams_wave_plan_set_guard(gams_gpu_t *h, gams_wave_plan_t *p, float safety, int all_exact) {
+    if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_plan_set_guard: null argument");
+    if (!(safety >= 1.0f) || !(safety <= 1e6f))
+        return gams_fail(h, GAMS_EINVAL, "wave_plan_set_guard: safety must be in [1, 1e6]");
+    p->guard_safety = safety;
+    p->guard_exact = all_exact != 0;
+    wave_set_band(p);
+    return GAMS_OK;
 }
 
 // One pass on way k: touches only that way's state and its stream (run_n drives different ways
@@ -551,6 +602,12 @@ static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
     a.g1 = p->g1;
     a.g2 = p->g2;
     a.g3 = p->g3;
+    a.aA = p->sq[0];
+    a.aB = p->sq[1];
+    a.gA0 = p->sq[2];
+    a.gA1 = p->sq[3];
+    a.gB0 = p->sq[4];
+    a.gB1 = p->sq[5];
     a.peaks = w.d_peaks;
     a.tile_cap = p->tile_cap;
     a.counters = w.d_counters + kSlotWords * slot;
@@ -573,20 +630,20 @@ static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
         }
     }
     int rc = GAMS_OK;
-    const bool headline = q.size == 100 && q.step == 10 && q.lag == 100;   // every BASELINE step-10 config
-    const bool step1 = q.size == 100 && q.step == 1 && q.lag == 100;       // BASELINE configs[3] (GRCh38, step 1)
+    const bool baked = p->fast_w && wave_is_baked(q, p->fast_w);
+    const bool step1 = baked && q.step == 1;
     if (p->direct)
         ;   // counted and decided above
     else if (p->fast_w == 20)
-        rc = step1 ? wave_launch_fast<20, 100, 1, 100>(h, p, a, st) : wave_launch_fast<20, 0, 0, 0>(h, p, a, st);
+        rc = baked ? wave_launch_fast<20, 100, 1, 100>(h, p, a, st) : wave_launch_fast<20, 0, 0, 0>(h, p, a, st);
     else if (p->fast_w == 12)
-        rc = headline ? wave_launch_fast<12, 100, 10, 100>(h, p, a, st)
-             : step1  ? wave_launch_fast<12, 100, 1, 100>(h, p, a, st)
-                      : wave_launch_fast<12, 0, 0, 0>(h, p, a, st);
+        rc = !baked ? wave_launch_fast<12, 0, 0, 0>(h, p, a, st)
+             : step1 ? wave_launch_fast<12, 100, 1, 100>(h, p, a, st)
+                     : wave_launch_fast<12, 100, 10, 100>(h, p, a, st);
     else if (p->fast_w == 8)
-        rc = headline ? wave_launch_fast<8, 100, 10, 100>(h, p, a, st) : wave_launch_fast<8, 0, 0, 0>(h, p, a, st);
+        rc = baked ? wave_launch_fast<8, 100, 10, 100>(h, p, a, st) : wave_launch_fast<8, 0, 0, 0>(h, p, a, st);
     else if (p->fast_w == 4)
-        rc = headline ? wave_launch_fast<4, 100, 10, 100>(h, p, a, st) : wave_launch_fast<4, 0, 0, 0>(h, p, a, st);
+        rc = baked ? wave_launch_fast<4, 100, 10, 100>(h, p, a, st) : wave_launch_fast<4, 0, 0, 0>(h, p, a, st);
     else if (p->k16)
         rc = p->wide ? wave_launch<uint16_t, true>(h, p, a, st) : wave_launch<uint16_t, false>(h, p, a, st);
     else

@@ -45,6 +45,10 @@ struct WaveArgs {
     uint32_t no_signal;   // lag == 1: std is NaN (0/0), the reference never signals
     float thr, thr_abs, fsize, flag_f, cvar;
     float g0, g1, g2, g3;  // guard band  G = g0 + g1*S1 + g2*R + g3*D
+    // the same band in the squared domain (wave_fast_kernel, see z_decide): decided signal <=>
+    // A > 0 and A^2 > V, decided none <=> B^2 < V, with A = aA*D - (gA0 + gA1*S1),
+    // B = aB*D + (gB0 + gB1*S1); every constant is already divided by thr*sqrt(n/(n-1))
+    float aA, aB, gA0, gA1, gB0, gB1;
     // outputs
     gams_peak_t *peaks;
     uint32_t tile_cap;             // records per tile slot of `peaks`
@@ -396,6 +400,33 @@ __global__ void wave_const_table_kernel(int8_t *const_sig, uint32_t size, uint32
     const_sig[k] = (int8_t)sg;
 }
 
+// The integer decision of wave_fast_kernel without a square root or an int<->float conversion.
+// Exact quantities: D = |n*k - S1|, V = n*S2 - S1^2 (integers).  The reference signals iff
+// D > R = thr*sqrt(n*V/(n-1)) up to its f32 rounding, bounded by the guard band
+// G = c + g*(D + R), c = g0 + g1*S1, g = g2 + g3 (wave_guard_band):
+//   D - R >  G  <=>  A := (D*(1-g) - c)/(1+g) > R  <=>  A > 0 and A^2 > R^2
+//   R - D >  G  <=>  B := (D*(1+g) + c)/(1-g) < R  <=>  B^2 < R^2
+// and with both sides divided by thr^2*n/(n-1) the right-hand side is V itself.  S1, S2, k are
+// carried as f32 (integers < 2^24, exact); V is formed with an error-free square
+// (P + Plo = S1^2 exactly), so its relative error is <= 2u; the host rounds aA down / aB, gA*,
+// gB* up by a few u (wave_squared_band), which covers the roundings of A, B and V.  The two
+// comparisons themselves are single fma's: the sign of fl(V - A*|A|) is the sign of the exact
+// value.  Returns raw words whose SIGN BITS say: xs = decided signal, xn = decided none,
+// dn = k below the mean.
+__device__ __forceinline__ void z_decide(float nf, float kkf, float S1f, float S2f, float aA, float aB,
+                                         float cA, float cB, uint32_t &xs, uint32_t &xn, uint32_t &dn) {
+    const float di = __builtin_fmaf(nf, kkf, -S1f);              // n*k - S1, exact
+    const float P = S1f * S1f;
+    const float V0 = __builtin_fmaf(nf, S2f, -P);                // n*S2 - P, one rounding
+    const float Plo = __builtin_fmaf(S1f, S1f, -P);              // S1^2 - P, exact
+    const float V = V0 - Plo;
+    const float A = __builtin_fmaf(__builtin_fabsf(di), aA, -cA);
+    const float B = __builtin_fmaf(__builtin_fabsf(di), aB, cB);
+    xs = __float_as_uint(__builtin_fmaf(-A, __builtin_fabsf(A), V));   // < 0  <=>  A > 0 and A^2 > V
+    xn = __float_as_uint(__builtin_fmaf(B, B, -V));                     // < 0  <=>  B^2 < V
+    dn = __float_as_uint(di);
+}
+
 // =============================================================================
 // wave_fast_kernel<W,SIZE,STEP,LAG>: the tile algorithm for 8-bit counts (size <= 255),
 // step <= 32 and 32-bit variance math (lag*size <= 65535, lag*size^2 < 2^24), i.e. every
@@ -428,16 +459,21 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
     static_assert((SIZE == 0) == (STEP == 0) && (SIZE == 0) == (LAG == 0), "bake all three or none");
     if (a.stamps != nullptr && threadIdx.x == 0)
         a.stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();  // workgroup entry
-    constexpr uint32_t TW = 256u * W;
+    // Windows per tile.  Baked parameters: 256*W - LAG - 1, so that the tile's K slots (its windows
+    // plus the lag+1 in front) are exactly 256*W: every thread of phase 2 owns W slots, which are
+    // also the block of outgoing counts of the phase-3 thread with the same index.
+    constexpr uint32_t TW = STEP != 0 ? 256u * W - (uint32_t)LAG - 1u : 256u * W;
     constexpr int WD = W / 4;
     extern __shared__ __align__(16) unsigned char smem[];
-    // LDS carve: BM (1 bit per base, 16 per chunk) | scratch (16 words) | K | SG (dense only)
+    // LDS carve: BM (1 bit per base, 16 per chunk) | scratch (16 words) | K | PS | SG (dense only)
     uint16_t *BM = reinterpret_cast<uint16_t *>(smem);
     const uint32_t *BW = reinterpret_cast<const uint32_t *>(smem);
     uint32_t *scr = reinterpret_cast<uint32_t *>(smem) + ((((a.max_chunks + 8u) >> 1) + 16u + 3u) & ~3u);
     uint8_t *K = reinterpret_cast<uint8_t *>(scr + 16);
     const uint32_t *KW = reinterpret_cast<const uint32_t *>(K);
-    uint8_t *SG = K + ((TW + (LAG ? (uint32_t)LAG : a.lag) + 1u + 31u) & ~15u);
+    // PS[t] = (sum k, sum k^2) over K slots [t*W, t*W + W)   (baked kernels; 256 + 16 entries)
+    uint2 *PS = reinterpret_cast<uint2 *>(K + ((256u * W + (LAG ? (uint32_t)LAG : a.lag) + 1u + 31u) & ~15u));
+    uint8_t *SG = reinterpret_cast<uint8_t *>(PS + 272);
 
     const uint32_t tid = threadIdx.x;
     const WaveTile tl = a.tiles[blockIdx.x];
@@ -509,8 +545,9 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
         // offset: ~6 VALU per window, no LDS access inside the run, counts stored 4 per dword.
         if (vb >= 0) {
             counted = true;
-            constexpr uint32_t NK_MAX = (uint32_t)LAG + 1u + TW;
-            constexpr uint32_t RUN = (((NK_MAX + 255u) / 256u) + 3u) & ~3u;
+            constexpr uint32_t NK_MAX = (uint32_t)LAG + 1u + TW;     // = 256 * W
+            constexpr uint32_t RUN = (uint32_t)W;
+            static_assert(NK_MAX == 256u * RUN, "phase 2: W slots per thread");
             constexpr uint32_t NBITS = RUN * (uint32_t)STEP + (uint32_t)SIZE;
             constexpr uint32_t NDW = (NBITS + 31u) / 32u + 1u;           // + 1 for the realignment
             const uint32_t nK = lag + 1u + nvalid;
@@ -533,18 +570,24 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
                 for (uint32_t d = 0; d < (uint32_t)SIZE / 32u; ++d) k += __popc(r[d]);
                 if constexpr (SIZE % 32 != 0) k += __popc(r[SIZE / 32] & ((1u << (SIZE % 32)) - 1u));
                 uint32_t packed = k;
+                uint32_t s1 = 0, s2 = 0;                                  // block sums for phase 3
 #pragma unroll
                 for (uint32_t j = 1; j < RUN; ++j) {
                     k += __popc(field((uint32_t)SIZE + (j - 1u) * (uint32_t)STEP));
                     k -= __popc(field((j - 1u) * (uint32_t)STEP));
                     if ((j & 3u) == 0u) {
                         if (idx0 + j - 4u < nK) reinterpret_cast<uint32_t *>(K)[(idx0 + j - 4u) >> 2] = packed;
+                        s1 = __builtin_amdgcn_udot4(packed, 0x01010101u, s1, false);
+                        s2 = __builtin_amdgcn_udot4(packed, packed, s2, false);
                         packed = k;
                     } else {
                         packed |= k << (8u * (j & 3u));
                     }
                 }
                 if (idx0 + RUN - 4u < nK) reinterpret_cast<uint32_t *>(K)[(idx0 + RUN - 4u) >> 2] = packed;
+                s1 = __builtin_amdgcn_udot4(packed, 0x01010101u, s1, false);
+                s2 = __builtin_amdgcn_udot4(packed, packed, s2, false);
+                PS[tid] = make_uint2(s1, s2);   // slots past nK only reach windows past the tile's end
             }
         }
     }
@@ -626,17 +669,42 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
         // S1, S2 over K[base, base+lag)
         uint32_t S1 = 0, S2 = 0;
         const uint32_t nfull = lag >> 2;
-#pragma unroll 5
-        for (uint32_t d = 0; d < nfull; ++d) {
-            const uint32_t x = KW[bw + d];
-            S1 = __builtin_amdgcn_udot4(x, 0x01010101u, S1, false);
-            S2 = __builtin_amdgcn_udot4(x, x, S2, false);
-        }
         const uint32_t sh = lag & 3u;                // wave-uniform
-        if (sh) {
-            const uint32_t x = KW[bw + nfull] & ((1u << (8u * sh)) - 1u);
-            S1 = __builtin_amdgcn_udot4(x, 0x01010101u, S1, false);
-            S2 = __builtin_amdgcn_udot4(x, x, S2, false);
+        bool summed = false;
+        if constexpr (STEP != 0) {
+            // Baked parameters: phase 2 left the sums of every thread's W slots in PS, so the lag
+            // counts in front of this thread's windows are LAG / W whole blocks (one 8-byte LDS read
+            // each, consecutive lanes on consecutive entries) plus LAG % W counts straight from K.
+            if (counted) {
+                summed = true;
+                constexpr uint32_t FULL = (uint32_t)LAG / (uint32_t)W, REM = (uint32_t)LAG % (uint32_t)W;
+#pragma unroll
+                for (uint32_t j = 0; j < FULL; ++j) {
+                    const uint2 ps = PS[tid + j];
+                    S1 += ps.x;
+                    S2 += ps.y;
+                }
+#pragma unroll
+                for (uint32_t d = 0; d < (REM + 3u) / 4u; ++d) {
+                    uint32_t x = KW[bw + FULL * (uint32_t)WD + d];
+                    if (d == REM / 4u && (REM & 3u)) x &= (1u << (8u * (REM & 3u))) - 1u;
+                    S1 = __builtin_amdgcn_udot4(x, 0x01010101u, S1, false);
+                    S2 = __builtin_amdgcn_udot4(x, x, S2, false);
+                }
+            }
+        }
+        if (!summed) {
+#pragma unroll 5
+            for (uint32_t d = 0; d < nfull; ++d) {
+                const uint32_t x = KW[bw + d];
+                S1 = __builtin_amdgcn_udot4(x, 0x01010101u, S1, false);
+                S2 = __builtin_amdgcn_udot4(x, x, S2, false);
+            }
+            if (sh) {
+                const uint32_t x = KW[bw + nfull] & ((1u << (8u * sh)) - 1u);
+                S1 = __builtin_amdgcn_udot4(x, 0x01010101u, S1, false);
+                S2 = __builtin_amdgcn_udot4(x, x, S2, false);
+            }
         }
         {
             const uint32_t ib = bw + nfull;
@@ -648,8 +716,6 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
                 lo = hi;
             }
         }
-        const float thr_abs = a.thr_abs, cvar = a.cvar;
-        const float g0 = a.g0, g1 = a.g1, g23 = a.g2 + a.g3;
         // windows this thread may decide: inside the tile, i >= lag, signalling enabled
         uint32_t can = 0;
         if (!a.no_signal && base < nvalid) {
@@ -657,35 +723,37 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
             const uint32_t lo_q = w0 + base >= lag ? 0u : min((uint32_t)W, lag - (w0 + base));  // q >= lo_q
             can = ((1u << hi_q) - 1u) & ~((1u << lo_q) - 1u);
         }
-        // per window three bits: sig (D - R > G), nos (R - D > G), dn (n*k < S1: sign bit of di).
-        // The S1 term of the guard band uses the thread's upper bound S1 + W*size (S1 grows by at
-        // most `size` per window): one conversion per thread instead of one per window.
+        // per window three sign bits (z_decide): sig (decided signal), nos (decided none), dn
+        // (n*k < S1).  The S1 term of the guard band uses the thread's upper bound S1 + W*size (S1
+        // grows by at most `size` per window): two fma's per thread instead of two per window.
+        // S1, S2 and the counts are carried as f32 from here on: integers below 2^24, every
+        // update exact (S2 drops the outgoing square before it takes the incoming one).
         uint32_t sigm = 0, nosm = 0, dnm = 0;
-        const float gconst = __builtin_fmaf(g1, (float)(S1 + (uint32_t)W * size), g0);
+        const float nf = (float)lag, aA = a.aA, aB = a.aB;
+        const float s1ub = (float)(S1 + (uint32_t)W * size);
+        const float cA = __builtin_fmaf(a.gA1, s1ub, a.gA0), cB = __builtin_fmaf(a.gB1, s1ub, a.gB0);
+        float S1f = (float)S1, S2f = (float)S2;
+        float kinf = (float)(in[0] & 0xFFu);
 #pragma unroll
         for (int q = 0; q < W; ++q) {
-            const uint32_t kout = (og[q >> 2] >> (8 * (q & 3))) & 0xFFu;
-            const uint32_t kin = (in[q >> 2] >> (8 * (q & 3))) & 0xFFu;
-            const uint32_t kk = (in[(q + 1) >> 2] >> (8 * ((q + 1) & 3))) & 0xFFu;
-            const int32_t di = (int32_t)__umul24(lag, kk) - (int32_t)S1;   // sign: side of the mean
-            const uint32_t V = __umul24(lag, S2) - __umul24(S1, S1);       // n*S2 - S1^2 >= 0
-            const float Df = fabsf((float)di);
-            const float Rf = thr_abs * __builtin_amdgcn_sqrtf(cvar * (float)V);
-            const float diff = Df - Rf;
-            const float G = __builtin_fmaf(g23, Df + Rf, gconst);
-            // one bit per test, shifted in MSB first: the sign bits of G - diff (diff > G),
-            // G + diff (diff < -G) and di; (acc << 1) | sign(x) is a single v_alignbit
-            sigm = __builtin_amdgcn_alignbit(sigm, __float_as_uint(G - diff), 31);
-            nosm = __builtin_amdgcn_alignbit(nosm, __float_as_uint(G + diff), 31);
-            dnm = __builtin_amdgcn_alignbit(dnm, (uint32_t)di, 31);
-            S1 += kin - kout;
-            S2 += __umul24(kin, kin) - __umul24(kout, kout);
+            const float koutf = (float)((og[q >> 2] >> (8 * (q & 3))) & 0xFFu);              // v_cvt_f32_ubyteN
+            const float kkf = (float)((in[(q + 1) >> 2] >> (8 * ((q + 1) & 3))) & 0xFFu);
+            uint32_t xs, xn, dn;
+            z_decide(nf, kkf, S1f, S2f, aA, aB, cA, cB, xs, xn, dn);
+            // one bit per test, shifted in MSB first: (acc << 1) | sign(x) is a single v_alignbit
+            sigm = __builtin_amdgcn_alignbit(sigm, xs, 31);
+            nosm = __builtin_amdgcn_alignbit(nosm, xn, 31);
+            dnm = __builtin_amdgcn_alignbit(dnm, dn, 31);
+            S1f = (S1f - koutf) + kinf;
+            S2f = __builtin_fmaf(-koutf, koutf, S2f);
+            S2f = __builtin_fmaf(kinf, kinf, S2f);
+            kinf = kkf;
         }
         // window q sits at bit W-1-q of the accumulators: flip to bit q
         sigm = __brev(sigm) >> (32 - W);
         nosm = __brev(nosm) >> (32 - W);
         dnm = __brev(dnm) >> (32 - W);
-        if (!(g0 < INFINITY)) sigm = nosm = 0;   // non-finite / negative threshold: every window is exact
+        if (!(a.g0 < INFINITY)) sigm = nosm = 0;   // thresholds outside the decidable range (wave_guard_band): every window is exact
         uint32_t decided = sigm | nosm;
         crest = sigm & ~dnm;                     // D > R + G > 0, so di != 0 here
         trough = sigm & dnm;
@@ -702,15 +770,14 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
                 s2 += kv * kv;
             }
             const uint32_t kk = K[base + qlag + lag + 1u];
-            const int32_t di = (int32_t)(lag * kk) - (int32_t)s1;
-            const uint32_t V = lag * s2 - s1 * s1;
-            const float Df = fabsf((float)di);
-            const float Rf = thr_abs * __builtin_amdgcn_sqrtf(cvar * (float)V);
-            const float diff = Df - Rf;
-            const float G = __builtin_fmaf(g1, (float)s1, __builtin_fmaf(g23, Df + Rf, g0));
-            decided = fabsf(diff) > G ? (decided | bit) : (decided & ~bit);
-            crest = (diff > 0.0f && di > 0) ? (crest | bit) : (crest & ~bit);
-            trough = (diff > 0.0f && di < 0) ? (trough | bit) : (trough & ~bit);
+            uint32_t xs, xn, dn;
+            z_decide(nf, (float)kk, (float)s1, (float)s2, aA, aB, __builtin_fmaf(a.gA1, (float)s1, a.gA0),
+                     __builtin_fmaf(a.gB1, (float)s1, a.gB0), xs, xn, dn);
+            const bool sg = (xs >> 31) != 0u, no = (xn >> 31) != 0u, below = (dn >> 31) != 0u;
+            const bool exact_all = !(a.g0 < INFINITY);
+            decided = ((sg || no) && !exact_all) ? (decided | bit) : (decided & ~bit);
+            crest = (sg && !below) ? (crest | bit) : (crest & ~bit);
+            trough = (sg && below) ? (trough | bit) : (trough & ~bit);
         }
         crest &= can & decided;
         trough &= can & decided;

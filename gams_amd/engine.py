@@ -170,6 +170,10 @@ class WavePlan:
                     mean_resident_wg=(sum_ticks / span_ticks) if span_ticks else 0.0)
         return list(m)[:7], info
 
+    def set_guard(self, safety=1.5, all_exact=False):
+        """diagnostics: safety factor of the guard band / every window through the exact path"""
+        self.eng.check(self.eng.lib.gams_wave_plan_set_guard(self.eng.h, self.p, safety, int(all_exact)))
+
     def exact_count(self):
         n = C.c_uint64()
         self.eng.check(self.eng.lib.gams_wave_exact_count(self.eng.h, self.p, C.byref(n)))

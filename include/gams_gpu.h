@@ -144,6 +144,12 @@ int gams_wave_dense(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t i,
  * windows of the last run took the exact-order f32 re-evaluation. */
 int gams_wave_plan_set_tile(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tile_windows);
 int gams_wave_exact_count(gams_gpu_t *h, gams_wave_plan_t *p, uint64_t *n_exact);
+/* Diagnostics of the integer decision's guard band (stat.rs:36-38 is an f32 comparison; windows
+ * whose integer margin is inside the band are re-evaluated in the reference's exact f32 order).
+ * safety (default 1.5, >= 1) multiplies the derived error bound; all_exact != 0 sends every window
+ * down the exact path.  Results are identical for every setting -- only the share of windows that
+ * take the exact path changes -- which is what the tests check.  Applies to the next run. */
+int gams_wave_plan_set_guard(gams_gpu_t *h, gams_wave_plan_t *p, float safety, int all_exact);
 /* Diagnostics: with stamps on, thread 0 of every workgroup records the shader clock at the
  * kernel's phase boundaries.  mean_cycles[0..5] = mean duration of load+classify, chunk
  * prefix, window counts, z-score, exact re-evaluation, outputs; [6] = whole workgroup;

@@ -23,7 +23,7 @@ small = synth.genome_ctgs(synth.S288C_LENGTHS, 500000)
 big = synth.genome_ctgs(synth.SYNTH384_LENGTHS, 1000000, first_chr_index=500)
 arms = []
 for path in args.libs:
-    lib = _lib.bind(os.path.abspath(path))
+    lib = _lib.bind(os.path.abspath(path), strict=False)
     eng = engine.Engine(0, lib=lib)
     for name, ctgs in (("S288c", small), ("384Mb", big)):
         ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])

@@ -11,7 +11,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gams_amd import _lib, engine, synth  # noqa: E402
 
 eng = engine.Engine(0)
-ctgs = synth.genome_ctgs(synth.S288C_LENGTHS, 500000)
+wl = sys.argv[2] if len(sys.argv) > 2 else "S288c"
+if wl == "384":
+    ctgs = synth.genome_ctgs(synth.SYNTH384_LENGTHS, 1000000, first_chr_index=500)
+elif wl == "Atha":
+    ctgs = synth.genome_ctgs(synth.ATHA_LENGTHS, 500000)
+else:
+    ctgs = synth.genome_ctgs(synth.S288C_LENGTHS, 500000)
 ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])
 tw = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 plan = engine.WavePlan(eng, ss, 100, 10, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS, tile_windows=tw)
@@ -46,12 +52,14 @@ print("distinct CUs used", len(uk), "wg per CU min/median/max", cnt.min(), np.me
 order = np.argsort(entry)
 print("first 12 entries", entry[order][:12].round(2), "\nlast 12", entry[order][-12:].round(2))
 # time line: number of resident workgroups every microsecond
-for t in np.arange(0, end.max(), 1.0):
+for t in np.arange(0, end.max(), max(1.0, round(end.max() / 40))):
     print(f"t={t:5.1f} resident={int(((entry <= t) & (end > t)).sum())}")
 # phases of the slowest workgroups (shader cycles)
 dur = (st[:, 1:7].astype(np.int64) - st[:, 0:6].astype(np.int64))
 tot = dur.sum(axis=1)
 worst = np.argsort(tot)[-8:]
+print("median phase cycles [load, (prefix), counts, z, exact, outputs]:", np.median(dur, axis=0).tolist(),
+      "mean", dur.mean(axis=0).round(0).tolist(), "lifetime us median", round(float(np.median(end - entry)), 2))
 print("phase cycles [load, (prefix), counts, z, exact, outputs] of the 8 slowest workgroups:")
 for w in worst:
     print("  ", dur[w].tolist(), "total", int(tot[w]))
