@@ -197,7 +197,7 @@ void wave_fill_tiles(gams_wave_plan_t *p) {
     for (uint32_t c = 0; c < p->set->n_ctg; ++c) {
         const uint32_t n = p->ctgs[c].n_win;
         for (uint32_t w = 0; w < n; w += p->tw)
-            p->tiles.push_back(WaveTile{c, w, n, (uint32_t)(p->ctgs[c].seq_off >> 8), p->ctgs[c].seq_off, p->ctgs[c].win_base});
+            p->tiles.push_back(WaveTile{c, w, n, 0u, p->ctgs[c].seq_off, p->ctgs[c].win_base});
     }
 }
 
@@ -403,10 +403,7 @@ int wave_launch_fast(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a, hipS
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
         p->attr_set = true;
     }
-    // persistent workgroups: at most 8 per CU (what LDS and the 64-VGPR cap admit); they take the
-    // remaining tiles themselves (see the kernel)
-    const unsigned grid = (unsigned)std::min<size_t>(p->tiles.size(), (size_t)8 * (size_t)std::max(h->cus, 1));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), p->lds_bytes, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)p->tiles.size()), dim3(256), p->lds_bytes, st, a);
     GAMS_HIP(h, hipGetLastError());
     return GAMS_OK;
 }
@@ -595,7 +592,6 @@ static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
     a.max_chunks = p->max_chunks;
     a.max_win = p->max_win;
     a.flags = p->serial ? GAMS_WAVE_DENSE : p->flags;
-    a.n_tiles = (uint32_t)p->tiles.size();
     a.no_signal = (q.lag < 2 || p->serial) ? 1u : 0u;
     a.thr = q.threshold;
     a.thr_abs = std::fabs(q.threshold);

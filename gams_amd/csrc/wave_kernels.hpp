@@ -20,7 +20,7 @@ struct WaveTile {
     uint32_t ctg;
     uint32_t w0;        // first window of the tile
     uint32_t n_win;     // windows of the ctg
-    uint32_t seq_off256;  // seq_off / 256: the first 16 bytes are all wave_fast_kernel needs of a tile
+    uint32_t pad;
     uint64_t seq_off;   // copy of the ctg's geometry: one load per workgroup instead of two dependent ones
     uint64_t win_base;
 };
@@ -42,7 +42,6 @@ struct WaveArgs {
     uint32_t max_chunks;  // LDS carve: PM holds max_chunks+1 words
     uint32_t max_win;     // LDS carve: K holds max_win, Q1/Q2 hold max_win+1
     uint32_t flags;
-    uint32_t n_tiles;     // wave_fast_kernel: tiles of the launch (its grid may be smaller: persistent workgroups)
     uint32_t no_signal;   // lag == 1: std is NaN (0/0), the reference never signals
     float thr, thr_abs, fsize, flag_f, cvar;
     float g0, g1, g2, g3;  // guard band  G = g0 + g1*S1 + g2*R + g3*D
@@ -63,19 +62,19 @@ struct WaveArgs {
 
 // Phase stamp of a diagnostic run (gams_wave_plan_set_stamps): thread 0 of the
 // workgroup stores the shader clock.  Off (stamps == NULL) it is one scalar branch.
-__device__ __forceinline__ void wave_stamp(const WaveArgs &a, uint32_t tile, int slot) {
+__device__ __forceinline__ void wave_stamp(const WaveArgs &a, int slot) {
     if (a.stamps != nullptr && threadIdx.x == 0) {
         // 16 words (one 128-B line) per workgroup: [0..6] shader clock at the phase
         // boundaries, [8] / [9] the constant 100 MHz clock at workgroup start / end
-        a.stamps[(size_t)tile * 16 + slot] = __builtin_readcyclecounter();
+        a.stamps[(size_t)blockIdx.x * 16 + slot] = __builtin_readcyclecounter();
         if (slot == 0) {
-            a.stamps[(size_t)tile * 16 + 8] = __builtin_amdgcn_s_memrealtime();
+            a.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memrealtime();
             // where it ran: HW_ID (wave/simd/cu/sh/se) and XCC_ID
-            a.stamps[(size_t)tile * 16 + 11] =
+            a.stamps[(size_t)blockIdx.x * 16 + 11] =
                 ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) |
                 (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
         }
-        if (slot == 6) a.stamps[(size_t)tile * 16 + 9] = __builtin_amdgcn_s_memrealtime();
+        if (slot == 6) a.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -458,6 +457,8 @@ template <int W, int SIZE, int STEP, int LAG>
 __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
     static_assert(W % 4 == 0 && (((W / 4) & 1) == 1 || W == 8), "W/4 odd (LDS bank stride), or W = 8 (64-bit reads)");
     static_assert((SIZE == 0) == (STEP == 0) && (SIZE == 0) == (LAG == 0), "bake all three or none");
+    if (a.stamps != nullptr && threadIdx.x == 0)
+        a.stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();  // workgroup entry
     // Windows per tile.  Baked parameters: 256*W - LAG - 1, so that the tile's K slots (its windows
     // plus the lag+1 in front) are exactly 256*W: every thread of phase 2 owns W slots, which are
     // also the block of outgoing counts of the phase-3 thread with the same index.
@@ -475,42 +476,11 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
     uint8_t *SG = reinterpret_cast<uint8_t *>(PS + 272);
 
     const uint32_t tid = threadIdx.x;
+    const WaveTile tl = a.tiles[blockIdx.x];
+    const struct { uint64_t seq_off, win_base; uint32_t n_win; } cg = {tl.seq_off, tl.win_base, tl.n_win};
     const uint32_t lag = LAG ? (uint32_t)LAG : a.lag, step = STEP ? (uint32_t)STEP : a.step,
                    size = SIZE ? (uint32_t)SIZE : a.size;
-    // Persistent workgroups.  The grid is at most 8 workgroups per CU; with more tiles than
-    // workgroups (`dyn`) a workgroup keeps taking tiles: b and G + b are its own, after that tile
-    // 2G + 8k + q with k from the counter of queue q.  There are eight queues, each counter on its
-    // own 128-B line (one shared counter serialises at ~88 returning atomics per us; a 384-Mb pass
-    // wants 200 tiles per us); a workgroup draws from the queue of the XCD it runs on and, once
-    // that is empty, from the next ones (the XCDs do not run at the same speed: without stealing
-    // the first one idles 16 us before the last one is done).  The next tile's descriptor (16 B) and
-    // the index of the tile after it are fetched behind the tile's own loads, so a new tile starts
-    // with its loads, not with two dependent memory round trips (kernel arguments, then the
-    // descriptor: 1.5 us median between workgroup entry and the first load on the 384-Mb genome
-    // when every tile was a workgroup of its own), and no slot of the chip waits for a dispatch
-    // (83 % of the slots were occupied then).  Results do not depend on which workgroup runs a
-    // tile: every tile owns its output slot.
-    const uint32_t G = gridDim.x, n_tiles = a.n_tiles;
-    const bool dyn = n_tiles > G;
-    uint32_t q = dyn ? (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u : 0u;   // HW_REG_XCC_ID
-    uint32_t dry = dyn ? 0u : 8u;                      // queues found empty so far; 8: nothing left to take
-    uint32_t tile = blockIdx.x;
-    uint32_t idx_next = dyn ? G + blockIdx.x : ~0u;
-    // Descriptors are read with vector loads (same address in every lane): a scalar load shares its
-    // counter with the LDS traffic, and its SGPRs would be spilled the moment it is issued.
-    uint32_t vzero = 0;
-    asm volatile("" : "+v"(vzero));                    // a zero the compiler takes for lane-dependent
-    uint4 tl;                                          // ctg, w0, n_win, seq_off / 256 (wave-uniform)
-    {
-        const uint4 d = *reinterpret_cast<const uint4 *>(a.tiles + tile + vzero);
-        tl = make_uint4((uint32_t)__builtin_amdgcn_readfirstlane((int)d.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)d.y),
-                        (uint32_t)__builtin_amdgcn_readfirstlane((int)d.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)d.w));
-    }
-    for (uint32_t it = 0;; ++it) {
-    if (a.stamps != nullptr && tid == 0)
-        a.stamps[(size_t)tile * 16 + 10] = __builtin_amdgcn_s_memrealtime();  // tile entry
-    const struct { uint64_t seq_off; uint32_t n_win; } cg = {(uint64_t)tl.w << 8, tl.z};
-    const uint32_t w0 = tl.y;
+    const uint32_t w0 = tl.w0;
     const uint32_t w1 = min(w0 + TW, cg.n_win);
     const uint32_t nvalid = w1 - w0;
     const int32_t vb = (int32_t)w0 - (int32_t)lag - 1;       // window held by K slot 0 (may be < 0)
@@ -521,32 +491,7 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
     const uint32_t nchunk = (b1 - a0 + 15u) >> 4;
     const uint4 *src = reinterpret_cast<const uint4 *>(a.seq + cg.seq_off + a0);
 
-    wave_stamp(a, tile, 0);
-    // Next tile's descriptor: the oldest vector load of the iteration, so it is there when the
-    // tile's own bytes are.  Lane 0 of the workgroup takes the index of the tile after it from the
-    // queue's counter behind the tile's own loads (WAVE_FETCH_NEXT).
-    const uint4 dnext = *reinterpret_cast<const uint4 *>(a.tiles + (dyn ? min(idx_next, n_tiles - 1u) : tile) + vzero);
-    uint32_t nk = 0;
-    const bool fetch = dyn && tid == 0;
-    unsigned long long *const tile_ctr = a.counters + (size_t)q * kShardWords;
-    // Written as asm: hipcc waits vmcnt(0) right behind an atomicAdd in a predicated block, i.e. for
-    // every load of the tile before the first one is classified.  It is issued after the compiler's
-    // own loads, so its vmcnt(N) waits stay conservative (one entry younger than it knows of), and
-    // the value is used behind an explicit vmcnt(0).  The s_nop covers the VALU-writes-SGPR ->
-    // VMEM-reads-it hazard (5 wait states): the counter's address may just have come out of a
-    // v_readlane (spilled SGPR), and the hazard recogniser does not look inside an asm statement.
-#define WAVE_TAKE_TILE(dst)                                                                            \
-    asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0"                                       \
-                 : "=v"(dst) : "v"(0u), "v"(1u), "s"(tile_ctr) : "memory")
-    // Issue priority.  Persistent waves all have the same age, so the SIMD's oldest-first arbitration
-    // degenerates into a fixed order and the waves at its end starve (tile lifetimes up to 50 us
-    // against a median of 8).  Each wave therefore raises its priority as its tile advances -- 0
-    // while the tile's bytes are in flight, 1 for the window counts, 2 for the z-scores, 3 for
-    // the outputs and the next tile's loads -- which restores "the tile that started first finishes
-    // first" and puts the loads in front of everything else.
-#define WAVE_FETCH_NEXT()                          \
-    if (fetch && dry < 8u) WAVE_TAKE_TILE(nk);     \
-    __builtin_amdgcn_s_setprio(0);
+    wave_stamp(a, 0);
     // ---- phase 1: load + classify ------------------------------------------
     if constexpr (STEP != 0) {
         // Baked parameters: the tile never has more than NCH chunks, so every thread issues
@@ -561,7 +506,6 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
         // (issued last, so the predicated block delays no other load)
         v[NLD - 1u] = make_uint4(0, 0, 0, 0);
         if (tid + 256u * (NLD - 1u) < NCH) v[NLD - 1u] = src[tid + 256u * (NLD - 1u)];
-        WAVE_FETCH_NEXT();
 #pragma unroll
         for (uint32_t k = 0; k < NLD; ++k) BM[tid + 256u * k] = (uint16_t)gc_mask16(v[k]);
     } else
@@ -574,7 +518,6 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
         uint4 cur[4], nxt[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) cur[k] = src[min(tid + 256u * k, last)];
-        WAVE_FETCH_NEXT();
         for (uint32_t c0 = tid; c0 < nchunk; c0 += 1024u) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) nxt[k] = src[min(c0 + 1024u + 256u * k, last)];
@@ -584,21 +527,9 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
             for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
         }
     }
-#undef WAVE_FETCH_NEXT
-    // scr[4 + parity]: index of the tile after the next.  Two slots: a wave reads its copy at the end
-    // of the tile, when wave 0 may already be publishing the following one.
-    if (fetch) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(nk) : : "memory");
-        scr[4u + (it & 1u)] = dry < 8u ? 2u * G + 8u * nk + q : ~0u;
-    }
     __syncthreads();
-    const uint4 tl_next = make_uint4((uint32_t)__builtin_amdgcn_readfirstlane((int)dnext.x),
-                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)dnext.y),
-                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)dnext.z),
-                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)dnext.w));
-    __builtin_amdgcn_s_setprio(1);
-    wave_stamp(a, tile, 1);
-    wave_stamp(a, tile, 2);
+    wave_stamp(a, 1);
+    wave_stamp(a, 2);
 
     // ---- phase 2: k of every slot, rolling over the bit stream ------------------
     // Thread t owns a run of consecutive slots.  Its first window is counted directly
@@ -718,8 +649,7 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
         }
     }
     __syncthreads();
-    __builtin_amdgcn_s_setprio(2);
-    wave_stamp(a, tile, 3);
+    wave_stamp(a, 3);
 
     // ---- phase 3: rolling sums + decision, W consecutive windows per thread ---
     const bool want_peaks = (a.flags & GAMS_WAVE_PEAKS) != 0;
@@ -874,7 +804,7 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
             }
         }
     }
-    wave_stamp(a, tile, 4);
+    wave_stamp(a, 4);
     // Guard-band windows: exact f32 order, one window at a time by the whole wave.
     {
         const uint32_t lane = tid & 63u;
@@ -896,11 +826,10 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
             bal = __ballot(pend != 0u);
         }
         if (n_exact && lane == 0)
-            atomicAdd(&a.counters[(tile & (kShards - 1u)) * kShardWords + 1u], (unsigned long long)n_exact);
+            atomicAdd(&a.counters[(blockIdx.x & (kShards - 1u)) * kShardWords + 1u], (unsigned long long)n_exact);
     }
 
-    __builtin_amdgcn_s_setprio(3);
-    wave_stamp(a, tile, 5);
+    wave_stamp(a, 5);
     // ---- phase 4a: dense rows, coalesced through LDS -------------------------
     if (want_dense) {
         if (base < nvalid) {
@@ -909,10 +838,9 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
                 SG[base + q] = (uint8_t)(((crest >> q) & 1u) | (((trough >> q) & 1u) ? 0xFFu : 0u));
         }
         __syncthreads();
-        const uint64_t win_base = a.ctgs[tl.x].win_base;   // dense rows only: not part of the 16-B descriptor
         for (uint32_t idx = tid; idx < nvalid; idx += 256u) {
-            a.dense_cnt[win_base + w0 + idx] = K[idx + lag + 1u];
-            a.dense_sig[win_base + w0 + idx] = (int8_t)SG[idx];
+            a.dense_cnt[cg.win_base + w0 + idx] = K[idx + lag + 1u];
+            a.dense_sig[cg.win_base + w0 + idx] = (int8_t)SG[idx];
         }
     }
 
@@ -922,9 +850,9 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
         const uint32_t mine = (uint32_t)__popc(both);
         uint32_t tot;
         const uint32_t ex = block_excl_scan_256<uint32_t>(mine, scr, tot);
-        if (tid == 0) a.tile_cnt[tile] = tot;
+        if (tid == 0) a.tile_cnt[blockIdx.x] = tot;
         if (mine) {
-            gams_peak_t *const region = a.peaks + (size_t)tile * a.tile_cap;
+            gams_peak_t *const region = a.peaks + (size_t)blockIdx.x * a.tile_cap;
             uint32_t pos = ex;
             uint32_t bits = both;
             while (bits) {
@@ -933,7 +861,7 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
                 const uint32_t code = (crest >> q) & 1u;
                 if (pos < a.tile_cap) {
                     gams_peak_t pk;
-                    pk.ctg = tl.x;
+                    pk.ctg = tl.ctg;
                     pk.window = w0 + base + (uint32_t)q;
                     pk.gc_count = K[base + (uint32_t)q + lag + 1u];
                     pk.signal = code == 1u ? 1 : -1;
@@ -943,48 +871,7 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
             }
         }
     }
-    wave_stamp(a, tile, 6);
-    // ---- next tile (every decision here is wave- and workgroup-uniform) ----------
-    if (!dyn) break;                     // the grid covers every tile
-    uint32_t idx_after = (uint32_t)__builtin_amdgcn_readfirstlane((int)scr[4u + (it & 1u)]);
-    if (idx_after >= n_tiles && dry < 8u) {   // the queue is empty: later indices come from the next one
-        q = (q + 1u) & 7u;
-        ++dry;
-    }
-    if (idx_next < n_tiles) {            // the normal case: descriptor and successor are at hand
-        tile = idx_next;
-        tl = tl_next;
-        idx_next = idx_after;
-        continue;
-    }
-    // The pipeline ran empty (the queue this workgroup drew from is exhausted): take the index just
-    // fetched if it is a tile, otherwise ask the remaining queues one by one, waiting for each answer.
-    while (idx_after >= n_tiles && dry < 8u) {
-        if (tid == 0) {
-            uint32_t k2;
-            unsigned long long *const tile_ctr = a.counters + (size_t)q * kShardWords;
-            WAVE_TAKE_TILE(k2);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(k2) : : "memory");
-            scr[6] = 2u * G + 8u * k2 + q;
-        }
-        __syncthreads();
-        idx_after = (uint32_t)__builtin_amdgcn_readfirstlane((int)scr[6]);
-        __syncthreads();
-        if (idx_after >= n_tiles) {
-            q = (q + 1u) & 7u;
-            ++dry;
-        }
-    }
-    if (idx_after >= n_tiles) break;     // every queue is empty
-    tile = idx_after;
-    {
-        const uint4 d = *reinterpret_cast<const uint4 *>(a.tiles + tile + vzero);
-        tl = make_uint4((uint32_t)__builtin_amdgcn_readfirstlane((int)d.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)d.y),
-                        (uint32_t)__builtin_amdgcn_readfirstlane((int)d.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)d.w));
-    }
-    idx_next = ~0u;                      // nothing prefetched: the next iteration fetches one index ahead again
-#undef WAVE_TAKE_TILE
-    }   // tile loop
+    wave_stamp(a, 6);
 }
 
 // ---- parameters whose halo does not fit a tile (large step or lag): no tiling ---------------
