@@ -1,12 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- GC windows/s of the `wave` hot path on MI355X (driver contract in the task brief).
 
-A step = one pass of the hot path over one batch: every ctg of a synthetic genome (resident in
+A step = one pass of the hot path over one batch: every ctg of one synthetic genome (resident in
 HBM) -> gc counts -> smoothed z-score signals -> compacted peak records, one kernel launch.
-Default workload (N = 1): BASELINE.json configs[1], an S288c-sized genome (12,157,105 bp, 17
-chromosomes, --piece 500000), size 100 / step 10 / lag 100 / threshold 3 / influence 1.
-With N > 1 every rank owns its own genome of that shape (ctgs shard with no exchange: weak
-scaling), launched one process per GPU by torch.distributed.run.
+
+Default workload (N = 1): BASELINE.json configs[2], an A. thaliana-sized genome (119,667,750 bp,
+7 chromosomes, --piece 500000), size 100 / step 10 / lag 100 / threshold 3 / influence 1 -- the
+largest step-10 configuration that BASELINE names for one GPU.  Three distinct genomes of that
+shape stay resident (360 MB, more than the 256 MiB Infinity Cache) and the steps rotate over them,
+so every pass streams its bytes from HBM the way batch after batch of ctgs does
+(src/cmd_gams/wave.rs:288-299); the three plans sit on three HIP streams of the handle, i.e. up to
+three passes are in flight.  Before the W warm-up steps the clocks are ramped with at least 50 ms
+of passes, whatever W is.
+
+N > 1 (one rank per GPU, torch.distributed.run):
+  default      weak scaling: N x 3 genomes of the same shape, assigned to the ranks by
+               gams_amd.shard.lpt_assign on their window counts (three each); no exchange on the
+               data path, the barrier and the max-over-ranks timing are the only collectives.
+  --workload GRCh38-step10 | GRCh38-step1
+               strong scaling (BASELINE configs[3]): ONE 3.09-Gb genome whose 2,937 ctgs are
+               LPT-sharded over the ranks by window count; total windows/s = all windows / the
+               slowest rank's time.
 
 Prints ONE JSON line on rank 0.
 """
@@ -20,8 +34,20 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# kernel arguments in device memory (gams_gpu_create sets it too, but torch may initialise HIP first)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+ROUND = "r02"
+
+WORKLOADS = {
+    # name: (chromosome lengths, piece, size, step, lag, scaling for N > 1)
+    "S288c": ("S288C_LENGTHS", 500000, 100, 10, 100, "weak"),
+    "Atha": ("ATHA_LENGTHS", 500000, 100, 10, 100, "weak"),
+    "synth384": ("SYNTH384_LENGTHS", 1000000, 100, 10, 100, "weak"),
+    "GRCh38-step10": ("GRCH38_LENGTHS", 1000000, 100, 10, 100, "strong"),
+    "GRCh38-step1": ("GRCH38_LENGTHS", 1000000, 100, 1, 100, "strong"),
+}
 
 
 def profiled_traffic(workload):
@@ -29,34 +55,51 @@ def profiled_traffic(workload):
     (profiles/*_pmc.json, made by tools/prof.sh): FETCH_SIZE and WRITE_SIZE are in KiB and were
     collected in separate passes; on gfx950 FETCH_SIZE counts half the bytes of a wide coalesced
     stream, so it is doubled (MI355X_MICROARCH.md, HBM section).  None if no profile matches."""
-    path = os.path.join(ROOT, "profiles", f"r01_{workload}_wave_pmc.json")
-    try:
-        with open(path) as fh:
-            p = json.load(fh)
-        return (2.0 * p["FETCH_SIZE"]["mean"] + p["WRITE_SIZE"]["mean"]) * 1024.0
-    except (OSError, KeyError, ValueError):
-        return None
-
-WORKLOADS = {
-    # name: (chromosome lengths, piece, size, step, lag)
-    "S288c": ("S288C_LENGTHS", 500000, 100, 10, 100),
-    "Atha": ("ATHA_LENGTHS", 500000, 100, 10, 100),
-    "synth384": ("SYNTH384_LENGTHS", 1000000, 100, 10, 100),
-    "GRCh38-step10": ("GRCH38_LENGTHS", 1000000, 100, 10, 100),
-    "GRCh38-step1": ("GRCH38_LENGTHS", 1000000, 100, 1, 100),
-}
+    for rnd in (ROUND, "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{workload}_wave_pmc.json")
+        try:
+            with open(path) as fh:
+                p = json.load(fh)
+            return (2.0 * p["FETCH_SIZE"]["mean"] + p["WRITE_SIZE"]["mean"]) * 1024.0
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
-def build_workload(name, rank, scale=1.0):
-    from gams_amd import synth
+def window_count(n, size, step):
+    return max(0, (n - size) // step + 1)
 
-    lengths_name, piece, size, step, lag = WORKLOADS[name]
+
+def build_batches(name, rank, world, copies, scale):
+    """-> (batches, params, genome_bp, scaling, shard_note); a batch = list of ctg dicts."""
+    from gams_amd import shard, synth
+
+    lengths_name, piece, size, step, lag, scaling = WORKLOADS[name]
     lengths = getattr(synth, lengths_name)
     if scale != 1.0:
         lengths = [max(20000, int(x * scale)) for x in lengths]
-    # each rank gets its own genome (different chromosome seeds)
-    ctgs = synth.genome_ctgs(lengths, piece, first_chr_index=1 + 1000 * rank)
-    return ctgs, dict(size=size, step=step, lag=lag, threshold=3.0, influence=1.0), sum(lengths)
+    prm = dict(size=size, step=step, lag=lag, threshold=3.0, influence=1.0)
+    if scaling == "strong":
+        # ONE genome; every rank cuts the same ctgs and keeps its LPT share (wave.rs:288-299: the ctg is
+        # the unit of work)
+        ctgs = synth.genome_ctgs(lengths, piece, first_chr_index=1)
+        weights = [window_count(len(c["seq"]), size, step) for c in ctgs]
+        owner = shard.lpt_assign(weights, world)
+        mine = [c for c, o in zip(ctgs, owner) if o == rank]
+        loads = [sum(w for w, o in zip(weights, owner) if o == r) for r in range(world)]
+        note = (f"{len(ctgs)} ctgs LPT-sharded x{world} by windows; rank loads max/mean "
+                f"{max(loads) / (sum(loads) / world):.4f}")
+        del ctgs
+        return [mine], prm, sum(lengths), "strong", note
+    # weak: world * copies genomes of the same shape; the unit handed to a rank is a genome (its
+    # chromosomes are seeded by the genome's index, so a rank generates only what it owns)
+    n_genomes = world * copies
+    per_genome = sum(window_count(x, size, step) for x in lengths)   # equal weights: LPT deals them round
+    owner = shard.lpt_assign([per_genome] * n_genomes, world)
+    mine = [g for g, o in enumerate(owner) if o == rank]
+    batches = [synth.genome_ctgs(lengths, piece, first_chr_index=1 + 1000 * g) for g in mine]
+    note = f"{n_genomes} genomes dealt to {world} rank(s) by lpt_assign; rank {rank} holds genomes {mine}"
+    return batches, prm, sum(lengths), "weak", note
 
 
 def cpu_baseline(ctgs, prm, budget_windows=6_000_000, min_seconds=10.0):
@@ -70,7 +113,7 @@ def cpu_baseline(ctgs, prm, budget_windows=6_000_000, min_seconds=10.0):
     results = []
     while True:
         n_here = 0
-        for i, c in enumerate(ctgs):
+        for c in ctgs:
             cnt, _, sig = ora.wave_windows(c["seq"], prm["size"], prm["step"], prm["lag"], prm["threshold"],
                                            prm["influence"])
             if passes == 0:
@@ -87,20 +130,120 @@ def cpu_baseline(ctgs, prm, budget_windows=6_000_000, min_seconds=10.0):
     return done / dt, used, done, results, passes, dt
 
 
+def secondary_metrics(eng):
+    """sw rows/s and interval queries/s on one GPU's share of BASELINE configs[2] /
+    configs[4]: device time of the kernel (HIP events around it), inputs resident, with the
+    algorithmic bytes per unit and the fraction of the HBM roofline that gives."""
+    import ctypes as C
+
+    from gams_amd import _lib, engine, synth
+
+    lib = eng.lib
+
+    def kernel_ms():
+        ms = C.c_float()
+        eng.check(lib.gams_gpu_last_kernel_ms(eng.h, C.byref(ms)))
+        return ms.value
+
+    def entry(units, ms, bytes_per_unit, unit, what):
+        rate = units / (ms * 1e-3)
+        gbps = rate * bytes_per_unit / 1e9
+        return {"value": rate, "unit": unit, "kernel_ms": ms, "bytes_per_unit": bytes_per_unit,
+                "achieved_GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS, "workload": what}
+
+    out = {}
+    # ---- sw: 1e5 point features over a 30-Mb chromosome (configs[2] shape, one chromosome) ----
+    chrom = synth.chromosome(30_427_671, 1)
+    ctgs = synth.gen_ctgs("1", chrom, piece=500000)
+    ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])
+    feats = synth.point_features(ctgs, 100000)
+    rows_total, ms_total = 0, 0.0
+    for rep in range(2):                      # second repetition is the measured one (gc index built, pools warm)
+        rows_total, ms_total = 0, 0.0
+        for i, c in enumerate(ctgs):
+            fs = feats[i]
+            if fs.size == 0:
+                continue
+            n = C.c_uint64()
+            rows = np.zeros(fs.size * 41, _lib.SW_ROW_DTYPE)
+            eng.check(lib.gams_gpu_sw(eng.h, ss.p, i, c["chr_start"], fs.ctypes.data, fs.ctypes.data, fs.size,
+                                      100, 20, 500, rows.ctypes.data, rows.size, C.byref(n)))
+            rows_total += n.value
+            ms_total += kernel_ms()
+    out["sw_rows_per_s"] = entry(rows_total, ms_total, 84, "rows/s",
+                                 f"{sum(f.size for f in feats)} point features, {len(ctgs)} ctgs of a 30.4-Mb "
+                                 f"chromosome, size 100 max 20 resize 500 ({rows_total} rows)")
+    ss.close()
+    # ---- intervals: configs[4] cut to one of 8 GPUs ----
+    w = synth.c5_workload(share=8)
+    nq = int(w["q_start"].size)
+    ix = C.c_void_p()
+    t0 = time.perf_counter()
+    eng.check(lib.gams_index_create(eng.h, w["n_ctg"], w["rg_off"].ctypes.data, w["rg_start"].ctypes.data,
+                                    w["rg_stop"].ctypes.data, C.byref(ix)))
+    build_s = time.perf_counter() - t0
+    qe_excl = w["q_end"]                      # locate/count pass (rg.start, rg.end): the end is exclusive (utils.rs:35)
+    cnt = np.zeros(nq, np.int32)
+    for _ in range(2):
+        eng.check(lib.gams_gpu_count(eng.h, ix, w["q_ctg"].ctypes.data, w["q_start"].ctypes.data,
+                                     qe_excl.ctypes.data, nq, cnt.ctypes.data))
+    out["count_queries_per_s"] = entry(nq, kernel_ms(), 16, "queries/s",
+                                       f"{nq} unsorted queries (length 1-2000) against {int(w['rg_start'].size)} stored "
+                                       f"point ranges in {w['n_ctg']} ctgs")
+    out["count_queries_per_s"]["index_build_s"] = build_s
+    t0 = time.perf_counter()
+    eng.check(lib.gams_gpu_count(eng.h, ix, w["q_ctg"].ctypes.data, w["q_start"].ctypes.data,
+                                 qe_excl.ctypes.data, nq, cnt.ctypes.data))
+    call_s = time.perf_counter() - t0
+    out["count_queries_per_s"]["whole_call_from_host_arrays_per_s"] = nq / call_s
+    lib.gams_index_destroy(eng.h, ix)
+    # locate: which ctg holds a range (idx:ctg:{chr}: one group per chromosome)
+    ixc = C.c_void_p()
+    eng.check(lib.gams_index_create(eng.h, w["n_chr"], w["ctg_off"].ctypes.data, w["ctg_start"].ctypes.data,
+                                    w["ctg_stop"].ctypes.data, C.byref(ixc)))
+    hit = np.zeros(nq, np.int64)
+    for _ in range(2):
+        eng.check(lib.gams_gpu_locate(eng.h, ixc, w["q_chr"].ctypes.data, w["q_start"].ctypes.data,
+                                      qe_excl.ctypes.data, nq, hit.ctypes.data))
+    out["locate_queries_per_s"] = entry(nq, kernel_ms(), 16, "queries/s",
+                                        f"{nq} ranges against {w['n_ctg']} ctgs of {w['n_chr']} chromosomes")
+    lib.gams_index_destroy(eng.h, ixc)
+    # anno: covered proportion of each range inside its ctg
+    sp = C.c_void_p()
+    eng.check(lib.gams_spans_create(eng.h, w["n_chr"], w["sp_off"].ctypes.data, w["sp_lo"].ctypes.data,
+                                    w["sp_hi"].ctypes.data, C.byref(sp)))
+    s = w["q_start"].astype(np.int32)
+    e = w["q_end"].astype(np.int32)
+    cl = (((s - 1) // w["piece"]) * w["piece"] + 1).astype(np.int32)
+    ch = (cl + (w["piece"] - 1)).astype(np.int32)
+    prop = np.zeros(nq, np.float32)
+    for _ in range(2):
+        eng.check(lib.gams_gpu_cover(eng.h, sp, w["q_chr"].ctypes.data, cl.ctypes.data, ch.ctypes.data,
+                                     s.ctypes.data, e.ctypes.data, nq, prop.ctypes.data))
+    out["anno_lines_per_s"] = entry(nq, kernel_ms(), 16, "lines/s",
+                                    f"{nq} lines against {int(w['sp_lo'].size)} spans in {w['n_chr']} chromosomes")
+    lib.gams_spans_destroy(eng.h, sp)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=5000,
-                    help="untimed passes before the timed region (the clocks take a few ms of load to settle)")
-    ap.add_argument("--workload", default="S288c", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="Atha", choices=sorted(WORKLOADS))
+    ap.add_argument("--copies", type=int, default=3,
+                    help="weak workloads: distinct genomes resident per GPU, the steps rotate over them")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink/grow chromosome lengths (testing)")
     ap.add_argument("--tile", type=int, default=0, help="windows per tile (0 = library default)")
-    ap.add_argument("--depth", type=int, default=4,
-                    help="passes in flight (gams_wave_plan_set_depth): consecutive steps rotate over this many HIP "
-                         "streams and output sets; 1 = one pass at a time")
+    ap.add_argument("--depth", type=int, default=0,
+                    help="passes in flight of a single-batch workload (gams_wave_plan_set_depth); 0 = 2. "
+                         "Multi-batch workloads put batch j on HIP stream j % 4 instead")
+    ap.add_argument("--one-at-a-time", action="store_true", help="every batch on one stream, depth 1 (profiling)")
+    ap.add_argument("--ramp-ms", type=float, default=50.0, help="time-based clock ramp before the warm-up steps")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-extra", action="store_true", help="skip the beyond-L3 extra measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the S288c / beyond-L3 extra measurements")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the sw / interval metrics")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,10 +272,18 @@ def main():
     eng = engine.Engine(device)
     arch, cus, hbm = eng.device_info()
 
-    ctgs, prm, genome_bp = build_workload(args.workload, rank, args.scale)
-    ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])
-    plan = engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS, tile_windows=args.tile, **prm)
-    n_windows = plan.total_windows
+    batches, prm, genome_bp, scaling, shard_note = build_batches(args.workload, rank, world, args.copies, args.scale)
+    sets = [engine.SeqSet(eng, [c["seq"] for c in b]) for b in batches]
+    plans = [engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS, tile_windows=args.tile, **prm) for ss in sets]
+    nb = len(plans)
+    win_per_batch = [int(p.total_windows) for p in plans]
+
+    def set_flight(on):
+        """on: batch j on stream j % 4 (or, with one batch, `depth` ways); off: everything serial on one stream"""
+        for j, p in enumerate(plans):
+            if nb == 1:
+                p.set_depth((args.depth or 2) if on else 1)
+            p.set_lane(j % 4 if on and nb > 1 else 0)
 
     def barrier():
         eng.sync()
@@ -141,16 +292,25 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # The timed region: K full passes, `depth` of them in flight (each on its own stream, into its
-    # own output buffers); every pass reads the whole batch and leaves its compacted peaks in HBM.
-    # gams_wave_run_n(K) is the host's step loop in C (K x gams_wave_run; beyond two passes in flight
-    # it queues from two host threads, because one thread queues a launch every 3.3 us and the
-    # device finishes a 12-Mb pass every 2.9 us).
-    plan.set_depth(args.depth)
-    plan.run_n(args.warmup)
+    def run_steps(n, start=0):
+        for i in range(n):
+            plans[(start + i) % nb].run()
+        return sum(win_per_batch[(start + i) % nb] for i in range(n))
+
+    in_flight = not args.one_at_a_time
+    set_flight(in_flight)
+    # time-based clock ramp (independent of --warmup): the chip needs tens of ms of load before its
+    # clocks and the driver's queues are in steady state
+    t_ramp = time.perf_counter()
+    ramp_steps = 0
+    while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms or ramp_steps < 2 * nb:
+        run_steps(nb * 8, ramp_steps)
+        ramp_steps += nb * 8
+        eng.sync()
+    run_steps(args.warmup, ramp_steps)
     barrier()
     t0 = time.perf_counter()
-    plan.run_n(args.steps)
+    my_windows = run_steps(args.steps, ramp_steps + args.warmup)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -158,73 +318,63 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        w = torch.tensor([float(n_windows)], dtype=torch.float64, device=red_dev)
+        w = torch.tensor([float(my_windows)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(w, op=dist.ReduceOp.SUM)
         total_windows = float(w.item())
     else:
-        total_windows = float(n_windows)
-    # every pass still held (the last `depth`) must carry the same peaks
-    held = []
-    for age in range(min(args.depth, args.steps)):
-        plan.select(age)
-        held.append(plan.peaks())
-    held_equal = all(np.array_equal(held[0], x) for x in held[1:])
+        total_windows = float(my_windows)
+    peaks = [p.peaks() for p in plans]
+    n_exact = sum(p.exact_count() for p in plans)
 
-    # Roofline leg: the dominant kernel's own launch duration, one pass at a time, HIP events on
-    # the stream it runs on (this is what rocprofv3 --kernel-trace reports per launch).
-    plan.set_depth(1)
-    serial_steps = max(1, min(args.steps, 200))
-    for _ in range(min(args.warmup, 20) + 1):
-        plan.run()
+    # Roofline leg: the dominant kernel's own launch duration, one pass at a time on the library's
+    # compute stream, HIP events on that stream (what rocprofv3 --kernel-trace reports per launch);
+    # the batches still rotate, so every launch streams from HBM.
+    set_flight(False)
+    serial_steps = max(nb * 4, min(max(args.steps, 30), 300))
+    run_steps(nb * 3)
     eng.sync()
     eng.timer_start()
-    for _ in range(serial_steps):
-        plan.run()
+    run_steps(serial_steps)
     kernel_ms = eng.timer_stop()      # HIP events on the library's compute stream
     eng.sync()
-
-    peaks = plan.peaks()
-    n_exact = plan.exact_count()
-    # beside `value`: the same pass with the compacted peaks packed and copied to the host every step
-    rb_steps = max(1, min(args.steps, 50))
-    eng.sync()
-    t0r = time.perf_counter()
-    for _ in range(rb_steps):
-        plan.run()
-        plan.peaks()
-    readback_wps = n_windows * rb_steps / (time.perf_counter() - t0r)
+    launch_ms = kernel_ms / serial_steps
+    serial_windows = sum(win_per_batch[i % nb] for i in range(serial_steps)) / serial_steps
 
     out = None
     if rank == 0:
         step_bytes = prm["step"]                       # `step` bytes read per window
-        launch_ms = kernel_ms / serial_steps           # one wave_fast_kernel launch per pass
-        achieved = n_windows * step_bytes / (launch_ms * 1e-3) / 1e9
+        achieved = serial_windows * step_bytes / (launch_ms * 1e-3) / 1e9
+        lengths_name, piece = WORKLOADS[args.workload][0], WORKLOADS[args.workload][1]
         out = {
-            "metric": "GC windows/s (size 100, step 10)",
-            "value": total_windows * args.steps / dt,
+            "metric": f"GC windows/s (size {prm['size']}, step {prm['step']})",
+            "value": total_windows / dt,
             "unit": "windows/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}-shaped synthetic genome per GPU ({genome_bp} bp, {len(ctgs)} ctgs, "
-                            f"piece {WORKLOADS[args.workload][1]}): wave size {prm['size']} step {prm['step']} "
-                            f"lag {prm['lag']} threshold 3 influence 1, peaks compacted on device",
-                "windows_per_gpu_per_step": int(n_windows),
-                "peaks_per_step": int(peaks.size),
-                "exact_path_windows": int(n_exact),
-                "passes_in_flight": args.depth,
-                "held_passes_identical": bool(held_equal),
-                "windows_per_s_one_pass_at_a_time": n_windows / (launch_ms * 1e-3),
-                "windows_per_s_with_host_readback": readback_wps,
+                "workload": f"{args.workload}-shaped synthetic genome ({genome_bp} bp, piece {piece}): wave size "
+                            f"{prm['size']} step {prm['step']} lag {prm['lag']} threshold 3 influence 1, peaks "
+                            f"compacted on device; {nb} batch(es) resident per GPU, steps rotate over them",
+                "batches_per_gpu": nb,
+                "ctgs_per_batch": [len(b) for b in batches],
+                "windows_per_step": win_per_batch,
+                "resident_bytes_per_gpu": int(sum(sum(len(c["seq"]) for c in b) for b in batches)),
+                "peaks_per_step": [int(p.size) for p in peaks],
+                "exact_path_windows_per_rotation": int(n_exact),
+                "passes_in_flight": (min(nb, 4) if nb > 1 else (args.depth or 2)) if in_flight else 1,
+                "clock_ramp_ms": args.ramp_ms,
+                "clock_ramp_steps": ramp_steps,
+                "windows_per_s_one_pass_at_a_time": serial_windows / (launch_ms * 1e-3),
+                "sharding": shard_note,
                 "device": arch,
-                "parallelism": f"ctg-sharded x{world}, no collective",
+                "parallelism": f"ctg-sharded x{world}, no collective on the data path",
             },
             "roofline": {
                 "bound": "hbm",
@@ -234,70 +384,90 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": profiled_traffic(args.workload) if args.scale == 1.0 and args.tile == 0 else None,
-                "algorithmic_bytes": int(n_windows) * step_bytes,
+                "algorithmic_bytes": int(serial_windows * step_bytes),
                 "bytes_per_window": step_bytes,
                 "launch_ms": launch_ms,
-                "achieved_with_passes_in_flight": int(n_windows) * step_bytes / (dt / args.steps) / 1e9,
+                "launches_timed": serial_steps,
+                "achieved_with_passes_in_flight": total_windows / world * step_bytes / dt / 1e9,
             },
         }
         if not args.no_cpu and world == 1:             # the CPU legs run on rank 0 at N=1 only
-            cpu_wps, used, done, res, cpu_passes, cpu_dt = cpu_baseline(ctgs, prm)
+            cpu_wps, used, done, res, cpu_passes, cpu_dt = cpu_baseline(batches[0], prm)
             # parity in the same run: peaks of the sampled ctgs against the oracle
             ok = True
             for c, (cnt, sig) in enumerate(res):
                 idx = np.flatnonzero(sig)
-                mine = peaks[peaks["ctg"] == c]
+                mine = peaks[0][peaks[0]["ctg"] == c]
                 ok &= bool(np.array_equal(mine["window"], idx) and np.array_equal(mine["signal"], sig[idx])
                            and np.array_equal(mine["gc_count"], cnt[idx]))
             out["cpu_baseline"] = {
                 "value": cpu_wps, "unit": "windows/s", "cores": 1, "kind": "port",
-                "sample": f"first {used} ctgs of the same workload, {cpu_passes} times over ({done} windows, "
+                "sample": f"first {used} ctgs of the first batch, {cpu_passes} time(s) over ({done} windows, "
                           f"{cpu_dt:.1f} s), oracle/gams_oracle.c single thread; host has {os.cpu_count()} cpus",
             }
-            # the reference's --parallel T model (one ctg per worker thread, wave.rs:288-299), for context
+            # the reference's --parallel T model (one ctg per worker thread, wave.rs:288-299) at T = all
+            # host cores, bounded to the first batch
             from concurrent.futures import ThreadPoolExecutor
             from oracle import oracle as ora
 
-            T = min(16, os.cpu_count() or 1, len(ctgs))
+            T = max(1, min(os.cpu_count() or 1, len(batches[0])))
             t0p = time.perf_counter()
             with ThreadPoolExecutor(T) as ex:
                 sizes = list(ex.map(lambda c: ora.wave_windows(c["seq"], prm["size"], prm["step"], prm["lag"],
-                                                               prm["threshold"], prm["influence"])[0].size, ctgs))
+                                                               prm["threshold"], prm["influence"])[0].size,
+                                    batches[0]))
             out["cpu_baseline_parallel"] = {"value": sum(sizes) / (time.perf_counter() - t0p), "unit": "windows/s",
                                             "cores": T, "kind": "port",
-                                            "sample": f"all {len(ctgs)} ctgs, one ctg per worker thread"}
+                                            "sample": f"all {len(batches[0])} ctgs of the first batch, one ctg per "
+                                                      f"worker thread, {T} threads on {os.cpu_count()} cpus"}
             out["parity_vs_oracle"] = ok
-    if rank == 0 and world == 1 and not args.no_extra and args.workload == "S288c" and args.scale == 1.0:
-        # The 12 Mb workload lives in L2/MALL and one launch lasts microseconds.  Also measure a
-        # genome larger than the 256 MiB Infinity Cache so that the HBM roofline fraction of the
-        # kernel itself can be read (reported beside, never as `value`).
-        plan.close()
+    for p in plans:
+        p.close()
+    for ss in sets:
         ss.close()
+    del batches
+    if rank == 0 and world == 1 and not args.no_extra and args.scale == 1.0:
         from gams_amd import synth
 
-        big = synth.genome_ctgs(synth.SYNTH384_LENGTHS, 1000000, first_chr_index=500)
-        ss = engine.SeqSet(eng, [c["seq"] for c in big])
-        plan = engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS, tile_windows=args.tile, **prm)
-        for _ in range(3):
-            plan.run()
-        eng.sync()
-        eng.timer_start()
-        reps = 20
-        for _ in range(reps):
-            plan.run()
-        ms = eng.timer_stop() / reps
-        nw = plan.total_windows
-        gbps = nw * prm["step"] / (ms * 1e-3) / 1e9
-        out["extra"] = {
-            "workload": f"synthetic {sum(len(c['seq']) for c in big)} bp ({len(big)} ctgs, piece 1000000), "
-                        f"beyond the 256 MiB L3",
-            "windows_per_s": nw / (ms * 1e-3), "launch_ms": ms, "achieved_GBps": gbps,
-            "frac_of_8TBps": gbps / HBM_PEAK_GBPS,
-        }
+        extra = {}
+        # (a) BASELINE configs[1]: the 12-Mb genome lives in L2/MALL and one launch lasts microseconds
+        #     (launch-latency bound); (b) a 384-Mb genome, one launch beyond the Infinity Cache.
+        for tag, lengths, piece, depth in (("S288c", synth.S288C_LENGTHS, 500000, 4),
+                                           ("synth384", synth.SYNTH384_LENGTHS, 1000000, 1)):
+            if tag == args.workload:
+                continue
+            g = synth.genome_ctgs(lengths, piece, first_chr_index=500 if tag == "synth384" else 1)
+            ss = engine.SeqSet(eng, [c["seq"] for c in g])
+            plan = engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS, tile_windows=args.tile, **prm)
+            for _ in range(20):
+                plan.run()
+            eng.sync()
+            reps = 200 if tag == "S288c" else 20
+            eng.timer_start()
+            for _ in range(reps):
+                plan.run()
+            ms = eng.timer_stop() / reps
+            nw = plan.total_windows
+            e = {"workload": f"{sum(len(c['seq']) for c in g)} bp, {len(g)} ctgs, piece {piece}",
+                 "windows_per_launch": int(nw), "launch_ms": ms, "windows_per_s": nw / (ms * 1e-3),
+                 "achieved_GBps": nw * prm["step"] / (ms * 1e-3) / 1e9,
+                 "frac_of_8TBps": nw * prm["step"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+            if depth > 1:
+                plan.set_depth(depth)
+                plan.run_n(2000)
+                eng.sync()
+                t0 = time.perf_counter()
+                plan.run_n(1000)
+                eng.sync()
+                e["windows_per_s_4_in_flight"] = nw * 1000 / (time.perf_counter() - t0)
+            extra[tag] = e
+            plan.close()
+            ss.close()
+        out["extra"] = extra
+    if rank == 0 and world == 1 and not args.no_secondary:
+        out["secondary"] = secondary_metrics(eng)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    plan.close()
-    ss.close()
     eng.close()
     if dist is not None:
         dist.barrier()

@@ -85,6 +85,7 @@ struct gams_wave_plan {
     };
     Way way[gams_gpu::kMaxWays];
     uint32_t depth = 1;                         // ways in use
+    uint32_t lane = 0;                          // way k runs on stream (lane + k) % kMaxWays (gams_wave_plan_set_lane)
     uint32_t last_way = 0;                      // way of the most recent run
     uint32_t sel_age = 0;                       // readers look at the run `sel_age` before the most recent one
     hipEvent_t ready = nullptr;                 // recorded on the compute stream behind the const table
@@ -303,7 +304,10 @@ void wave_set_band(gams_wave_plan_t *p) {
 inline size_t wave_align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // the stream way k runs on: the handle's compute stream, or one of its auxiliary streams
-hipStream_t wave_stream(gams_gpu_t *h, uint32_t k) { return k == 0 ? h->compute : h->aux[k - 1]; }
+hipStream_t wave_stream(gams_gpu_t *h, const gams_wave_plan_t *p, uint32_t k) {
+    const uint32_t si = (p->lane + k) % (uint32_t)gams_gpu::kMaxWays;
+    return si == 0 ? h->compute : h->aux[si - 1];
+}
 
 // the way the readers look at
 gams_wave_plan::Way &wave_read_way(gams_wave_plan_t *p) {
@@ -314,7 +318,7 @@ uint32_t wave_read_way_index(const gams_wave_plan_t *p) {
 }
 
 int wave_sync_ways(gams_gpu_t *h, gams_wave_plan_t *p) {
-    for (uint32_t k = 0; k < p->depth; ++k) GAMS_HIP(h, hipStreamSynchronize(wave_stream(h, k)));
+    for (uint32_t k = 0; k < p->depth; ++k) GAMS_HIP(h, hipStreamSynchronize(wave_stream(h, p, k)));
     return GAMS_OK;
 }
 
@@ -366,7 +370,7 @@ int wave_alloc_ways(gams_gpu_t *h, gams_wave_plan_t *p) {
                                         reinterpret_cast<void **>(&w.d_counters), &w.d_counters_bytes));
             // queued in front of the way's first run on its own stream
             GAMS_HIP(h, hipMemsetAsync(w.d_counters, 0, kCounterRing * kSlotWords * sizeof(unsigned long long),
-                                       wave_stream(h, k)));
+                                       wave_stream(h, p, k)));
             w.runs = 0;
         }
         if (need_dense && !w.d_dense_cnt) {
@@ -498,7 +502,7 @@ void gams_wave_plan_destroy(gams_gpu_t *h, gams_wave_plan_t *p) {
     if (h) {
         (void)hipSetDevice(h->device);
         for (uint32_t k = 0; k < p->depth; ++k)
-            if (wave_stream(h, k)) (void)hipStreamSynchronize(wave_stream(h, k));
+            if (wave_stream(h, p, k)) (void)hipStreamSynchronize(wave_stream(h, p, k));
         if (h->readback) (void)hipStreamSynchronize(h->readback);
     }
     gams_pool_free(h, false, p->arena_fixed, p->arena_fixed_bytes);
@@ -557,9 +561,9 @@ int gams_wave_plan_set_guard(gams_gpu_t *h, gams_wave_plan_t *p, float safety, i
 // from different host threads); everything else it reads is fixed once the plan exists.
 static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
     gams_wave_plan::Way &w = p->way[k];
-    hipStream_t st = wave_stream(h, k);
+    hipStream_t st = wave_stream(h, p, k);
     // inputs: the way's stream queues behind the uploads and the plan's const table (no host wait)
-    if (k == 0) {
+    if (st == h->compute) {
         int wrc = gams_seqset_wait_uploads(h, p->set);
         if (wrc != GAMS_OK) return wrc;
     } else if (w.seen_upload != p->set->upload_gen && p->set->uploaded) {
@@ -677,7 +681,7 @@ static int wave_wait_last_run(gams_gpu_t *h, gams_wave_plan_t *p) {
     if (p->pipelined && w.done)
         GAMS_HIP(h, hipEventSynchronize(w.done));
     else
-        GAMS_HIP(h, hipStreamSynchronize(wave_stream(h, wave_read_way_index(p))));
+        GAMS_HIP(h, hipStreamSynchronize(wave_stream(h, p, wave_read_way_index(p))));
     return GAMS_OK;
 }
 
@@ -860,6 +864,25 @@ int gams_wave_plan_set_depth(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t depth)
     return rc;
 }
 
+int gams_wave_plan_set_lane(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t lane) {
+    if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_plan_set_lane: null argument");
+    if (lane >= (uint32_t)gams_gpu::kMaxWays)
+        return gams_fail(h, GAMS_EINVAL, "wave_plan_set_lane: lane must be 0.." + std::to_string(gams_gpu::kMaxWays - 1));
+    GAMS_HIP(h, hipSetDevice(h->device));
+    int rc = wave_sync_ways(h, p);
+    if (rc != GAMS_OK) return rc;
+    for (uint32_t k = 1; k < (uint32_t)gams_gpu::kMaxWays; ++k)
+        if (!h->aux[k - 1]) GAMS_HIP(h, hipStreamCreateWithFlags(&h->aux[k - 1], hipStreamNonBlocking));
+    p->lane = lane;
+    // the ways now run on other streams: they have to queue behind the uploads and the const table again
+    for (auto &w : p->way) {
+        w.seen_upload = 0;
+        w.seen_ready = false;
+    }
+    p->set->dirty = true;
+    return GAMS_OK;
+}
+
 int gams_wave_plan_select(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t age) {
     if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_plan_select: null argument");
     if (age >= p->depth || age >= p->run_idx)
@@ -889,7 +912,7 @@ int gams_wave_peaks(gams_gpu_t *h, gams_wave_plan_t *p, const gams_peak_t **peak
             GAMS_HIP(h, hipStreamWaitEvent(h->readback, w.done, 0));
         } else {
             if (!w.ran_ev) GAMS_HIP(h, hipEventCreateWithFlags(&w.ran_ev, hipEventDisableTiming));
-            GAMS_HIP(h, hipEventRecord(w.ran_ev, wave_stream(h, wave_read_way_index(p))));
+            GAMS_HIP(h, hipEventRecord(w.ran_ev, wave_stream(h, p, wave_read_way_index(p))));
             GAMS_HIP(h, hipStreamWaitEvent(h->readback, w.ran_ev, 0));
         }
         if (!p->d_dense) {
@@ -1052,7 +1075,7 @@ int gams_wave_exact_count(gams_gpu_t *h, gams_wave_plan_t *p, uint64_t *n_exact)
     if (!h || !p || !n_exact) return gams_fail(h, GAMS_EINVAL, "wave_exact_count: null argument");
     GAMS_HIP(h, hipSetDevice(h->device));
     gams_wave_plan::Way &w = wave_read_way(p);
-    GAMS_HIP(h, hipStreamSynchronize(wave_stream(h, wave_read_way_index(p))));
+    GAMS_HIP(h, hipStreamSynchronize(wave_stream(h, p, wave_read_way_index(p))));
     std::vector<unsigned long long> cnt(kSlotWords);
     GAMS_HIP(h, hipMemcpy(cnt.data(), w.d_counters + kSlotWords * w.last_ring,
                           kSlotWords * sizeof(unsigned long long), hipMemcpyDeviceToHost));

@@ -132,6 +132,10 @@ class WavePlan:
         """passes in flight: consecutive run() calls rotate over `depth` streams and output sets"""
         self.eng.check(self.eng.lib.gams_wave_plan_set_depth(self.eng.h, self.p, depth))
 
+    def set_lane(self, lane):
+        """run this plan on HIP stream `lane` (+ way) of the handle: plans on different lanes overlap"""
+        self.eng.check(self.eng.lib.gams_wave_plan_set_lane(self.eng.h, self.p, lane))
+
     def select(self, age):
         """point peaks()/dense()/exact_count() at the run `age` runs before the most recent one"""
         self.eng.check(self.eng.lib.gams_wave_plan_select(self.eng.h, self.p, age))

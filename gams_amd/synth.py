@@ -96,10 +96,124 @@ def gen_ctgs(chr_id, seq, piece=500000, fill=50, min_len=5000):
     return ctgs
 
 
-def genome_ctgs(lengths, piece, seed=SEED, first_chr_index=1):
-    """All ctgs of a synthetic genome, chromosome by chromosome."""
-    ctgs = []
-    for k, length in enumerate(lengths):
-        chrom = chromosome(length, first_chr_index + k, seed)
-        ctgs += gen_ctgs(str(first_chr_index + k), chrom, piece=piece)
-    return ctgs
+def genome_ctgs(lengths, piece, seed=SEED, first_chr_index=1, workers=None):
+    """All ctgs of a synthetic genome, chromosome by chromosome (chromosomes are seeded on their
+    own, so they are generated on `workers` threads; numpy releases the GIL in the heavy calls)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(k):
+        chrom = chromosome(lengths[k], first_chr_index + k, seed)
+        return gen_ctgs(str(first_chr_index + k), chrom, piece=piece)
+
+    if workers is None:
+        workers = min(16, os.cpu_count() or 1)
+    workers = max(1, min(workers, len(lengths)))
+    if workers == 1:
+        parts = [one(k) for k in range(len(lengths))]
+    else:
+        # longest chromosomes first, results back in chromosome order
+        order = sorted(range(len(lengths)), key=lambda k: -lengths[k])
+        with ThreadPoolExecutor(workers) as ex:
+            done = dict(zip(order, ex.map(one, order)))
+        parts = [done[k] for k in range(len(lengths))]
+    return [c for part in parts for c in part]
+
+
+def layout_ctg_lengths(lengths, piece, min_len=5000):
+    """Lengths of the ctgs `genome_ctgs` cuts, from the planted 10-kb N runs alone (one per 20 Mb)
+    and the --piece rule of gen.rs:108-126 -- no bases generated.  Short N runs (1-49 bp) are
+    filled by `gen`; two of them abutting into a run of 50 or more (which would split a ctg) is
+    rare and ignored here, so this is the layout a sharding test can use at full GRCh38 size."""
+    out = []
+    for length in lengths:
+        cuts = []
+        for k in range(1, length // 20_000_000 + 1):
+            s = k * 20_000_000 - 5000
+            if s + 10000 < length:
+                cuts.append((s + 1, s + 10000))            # 1-based inclusive N run
+        regions, pos = [], 1
+        for a, b in cuts:
+            regions.append((pos, a - 1))
+            pos = b + 1
+        regions.append((pos, length))
+        for lo, hi in regions:
+            if hi - lo + 1 < min_len:
+                continue
+            cur, p0 = [], lo
+            while hi - p0 + 1 > piece:
+                cur.append([p0, p0 + piece - 1])
+                p0 += piece
+            if not cur:
+                cur.append([p0, hi])
+            else:
+                cur[-1][1] = hi
+            out += [e - s + 1 for s, e in cur]
+    return out
+
+
+def point_features(ctgs, n, seed=SEED + 1):
+    """n uniform point ranges over the genome (features of `sw`), returned per ctg
+    as sorted int32 chromosome coordinates (start == end); positions falling between ctgs are dropped
+    the way the reference's loaders drop unlocated ranges."""
+    rng = np.random.default_rng(seed)
+    total = sum(len(c["seq"]) for c in ctgs)
+    out = []
+    for c in ctgs:
+        k = int(round(n * len(c["seq"]) / total))
+        pos = np.sort(rng.integers(c["chr_start"], c["chr_end"] + 1, k)).astype(np.int32)
+        out.append(pos)
+    return out
+
+
+def c5_workload(share=8, seed=SEED + 5, n_chr=32, chr_len=1_000_000_000, piece=1_000_000,
+                n_rg=100_000_000, n_query=100_000_000, spans_per_chr=1_000_000):
+    """SURVEY 8(d) C5 (BASELINE configs[4]) cut to one GPU's share: coordinates only, no sequence.
+    32 chromosomes x 1e9 bp in 1-Mb ctgs (32,000 ctgs); 1e8 stored point ranges; 1e8 queries of
+    length 1-2000; 1e6 disjoint spans per chromosome, length 100-3000.  `share` = number of GPUs the
+    whole is divided over: this rank's slice holds n_chr/share chromosomes and 1/share of
+    everything else.  (The survey's span lengths of 100-3000 cannot be disjoint at 1e6 spans per
+    1e9 bp -- they would cover 155 % -- so the spans here are 100-900 long, one in every 1000-bp
+    slot: half of every chromosome is covered.)  Returns a dict of numpy arrays:
+      ctg index (groups = ctgs): rg_off u64[n_ctg+1], rg_start/rg_stop u32 (stop = end+1, redis.rs:291-294)
+      chr index (groups = chrs): ctg_off u64[n_chr+1], ctg_start/ctg_stop u32 (redis.rs:245-248)
+      queries: q_chr u32, q_ctg u32 (the ctg holding q_start), q_start/q_end u32 (inclusive end)
+      spans: sp_off u64[n_chr+1], sp_lo/sp_hi i32 (inclusive, sorted, disjoint)"""
+    rng = np.random.default_rng(seed)
+    chrs = max(1, n_chr // share)
+    per_chr = chr_len // piece
+    n_ctg = chrs * per_chr
+    m = n_rg // share
+    nq = n_query // share
+    # stored point ranges: uniform over the slice, grouped by ctg
+    g = np.sort(rng.integers(0, n_ctg, m, dtype=np.int64))
+    rg_off = np.searchsorted(g, np.arange(n_ctg + 1)).astype(np.uint64)
+    ctg_first = (g % per_chr) * piece + 1                                  # chr coordinate of the ctg's first base
+    rg_start = (ctg_first + rng.integers(0, piece, m)).astype(np.uint32)
+    # ctgs per chromosome
+    k = np.arange(n_ctg, dtype=np.int64)
+    ctg_start = ((k % per_chr) * piece + 1).astype(np.uint32)
+    ctg_stop = (ctg_start.astype(np.int64) + piece).astype(np.uint32)      # chr_end + 1
+    ctg_off = (np.arange(chrs + 1, dtype=np.uint64) * np.uint64(per_chr))
+    # queries
+    q_chr = rng.integers(0, chrs, nq, dtype=np.int64)
+    q_start = rng.integers(1, chr_len - 2000, nq, dtype=np.int64)
+    q_end = q_start + rng.integers(0, 2000, nq, dtype=np.int64)           # length 1..2000
+    q_ctg = q_chr * per_chr + (q_start - 1) // piece
+    # runlist set: disjoint spans per chromosome
+    sp_lo, sp_hi = [], []
+    slot = chr_len // spans_per_chr                                        # one span inside every slot
+    base = np.arange(spans_per_chr, dtype=np.int64) * slot + 1
+    for _ in range(chrs):
+        ln = rng.integers(100, max(101, min(3001, slot - 99)), spans_per_chr, dtype=np.int64)
+        ofs = rng.integers(0, slot - ln - 1)
+        lo = base + ofs
+        sp_lo.append(lo.astype(np.int32))
+        sp_hi.append((lo + ln - 1).astype(np.int32))
+    sp_off = (np.arange(chrs + 1, dtype=np.uint64) * np.uint64(spans_per_chr))
+    return dict(n_chr=chrs, n_ctg=n_ctg, per_chr=per_chr, piece=piece,
+                rg_off=rg_off, rg_start=rg_start, rg_stop=(rg_start + np.uint32(1)),
+                ctg_off=ctg_off, ctg_start=ctg_start, ctg_stop=ctg_stop,
+                q_chr=q_chr.astype(np.uint32), q_ctg=q_ctg.astype(np.uint32),
+                q_start=q_start.astype(np.uint32), q_end=q_end.astype(np.uint32),
+                sp_off=sp_off, sp_lo=np.concatenate(sp_lo), sp_hi=np.concatenate(sp_hi))

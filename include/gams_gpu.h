@@ -128,6 +128,11 @@ int gams_wave_run_n(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t n);
  * Changing the depth drops the results held so far. */
 int gams_wave_plan_set_depth(gams_gpu_t *h, gams_wave_plan_t *plan, uint32_t depth);
 int gams_wave_plan_select(gams_gpu_t *h, gams_wave_plan_t *plan, uint32_t age);
+/* Several plans in flight on one handle (batch k+1 computing while batch k is read back): a plan's
+ * runs go to HIP stream (lane + way) % 4 of the handle, lane 0 by default.  Plans on different lanes
+ * overlap on the device exactly like the ways of one plan; the readers wait for their own plan only.
+ * Call while the plan is idle (it waits for the plan's queued runs). */
+int gams_wave_plan_set_lane(gams_gpu_t *h, gams_wave_plan_t *plan, uint32_t lane);
 /* Pipelined plans record an event behind every run, and gams_wave_peaks / gams_wave_dense wait
  * for that run only (so a host can keep several plans in flight on one handle: upload of batch
  * k+1 and its kernel overlap the readback and formatting of batch k).  Off by default: the

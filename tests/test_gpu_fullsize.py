@@ -91,3 +91,34 @@ def test_config3_step1_geometry_one_chromosome(eng):
         other, _ = gpu_peaks(eng, ss, 100, 1, 100, 3.0, tile)
         assert np.array_equal(other, pk), tile
     ss.close()
+
+
+def test_guard_band_margin_on_the_atha_genome(eng):
+    """on the configs[2] genome the default guard band (safety 1.5), the bare bound
+    (safety 1.0) and the all-exact run give identical peaks (= the oracle's, checked above), and the
+    default run sends fewer than 1e-3 of the windows down the exact path (stat.rs:36-38)."""
+    ctgs = synth.genome_ctgs(synth.ATHA_LENGTHS, 500000)
+    ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])
+    plan = engine.WavePlan(eng, ss, 100, 10, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS)
+    plan.run()
+    ref = plan.peaks()
+    n = plan.total_windows
+    n_default = plan.exact_count()
+    assert 0 < n_default < 1e-3 * n
+    plan.set_guard(1.0, False)
+    plan.run()
+    assert np.array_equal(plan.peaks(), ref)
+    assert plan.exact_count() <= n_default
+    plan.close()
+    # all-exact at full size is minutes of one-window-per-wave work: the largest chromosome's first 40 ctgs
+    sub = ctgs[:40]
+    s2 = engine.SeqSet(eng, [c["seq"] for c in sub])
+    p2 = engine.WavePlan(eng, s2, 100, 10, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS)
+    p2.set_guard(1.5, True)
+    p2.run()
+    got = p2.peaks()
+    assert np.array_equal(got, ref[ref["ctg"] < 40])
+    assert 0.99 * (p2.total_windows - 100 * len(sub)) <= p2.exact_count() <= p2.total_windows - 100 * len(sub)
+    p2.close()
+    s2.close()
+    ss.close()

@@ -410,3 +410,22 @@ def test_sw_rejects_features_whose_middle_is_outside_the_ctg(eng, s288c):
         with pytest.raises(Exception) as ei:
             host.sw(eng, c, [("f:x", s, e)])
         assert "middle outside the ctg" in str(ei.value)
+
+
+def test_wave_multi_one_handle_per_device(eng, s288c):
+    """the multi-device host path with handle k on device k % device_count (hipSetDevice
+    per handle); on the one-GPU test box every handle lands on device 0, on an 8-GPU node on all eight."""
+    import torch
+    from gams_amd import synth
+
+    n_dev = max(1, torch.cuda.device_count())
+    ctgs = all_ctgs(s288c, piece=50000) + synth.genome_ctgs([3_000_000], 500000, first_chr_index=70)
+    single = host.wave(eng, ctgs)
+    engines = [engine.Engine(k % n_dev) for k in range(4)]
+    try:
+        assert {e.device for e in engines} == set(range(min(4, n_dev)))
+        assert host.wave_multi(engines, ctgs) == single
+        assert host.wave_multi(engines[:3], ctgs, batch_bytes=500_000) == single
+    finally:
+        for e in engines:
+            e.close()

@@ -426,3 +426,81 @@ def test_call_order_and_argument_errors(eng, s288c):
     assert plan.peaks().size > 0                                                               # still fine
     plan.close()
     ss.close()
+
+
+def test_set_tile_that_leaves_the_tiled_kernels(eng):
+    """a PEAKS-only plan whose requested tile pushes it to the untiled kernels (prefix arrays
+    beyond the 160-KB LDS: size 100, step 1, lag 7000 is tiled at the default tile, untiled at 8192) must
+    get the dense rows those kernels write.  Compared with the oracle either way."""
+    seq = synth(60000, 21).tobytes()
+    ss = engine.SeqSet(eng, [seq])
+    plan = engine.WavePlan(eng, ss, 100, 1, 7000, 3.0, 1.0, flags=_lib.WAVE_PEAKS)
+    ocnt, _, osig = ora.wave_windows(seq, 100, 1, 7000, 3.0, 1.0)
+    idx = np.flatnonzero(osig)
+    for tile in (0, 8192, 4096, 8192):
+        if tile:
+            eng.check(eng.lib.gams_wave_plan_set_tile(eng.h, plan.p, tile))
+        plan.run()
+        pk = plan.peaks()
+        assert np.array_equal(pk["window"], idx) and np.array_equal(pk["signal"], osig[idx]), tile
+        assert np.array_equal(pk["gc_count"], ocnt[idx]), tile
+    plan.close()
+    ss.close()
+
+
+def test_plans_on_lanes_overlap_and_keep_their_results(eng, s288c):
+    """gams_wave_plan_set_lane: three plans over three different batches on three streams of the handle
+    (bench.py's rotation); every plan's peaks equal those of the same plan run alone on lane 0."""
+    seqs = [[bytes(s288c["I"])], [synth(300000, 31).tobytes(), synth(70000, 32).tobytes()],
+            [bytes(s288c["Mito"]), synth(150000, 33).tobytes()]]
+    sets = [engine.SeqSet(eng, s) for s in seqs]
+    plans = [engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS) for ss in sets]
+    ref = []
+    for p in plans:
+        p.run()
+        ref.append(p.peaks())
+    for j, p in enumerate(plans):
+        p.set_lane(j + 1)
+    for rep in range(50):
+        for p in plans:
+            p.run()
+    for j, p in enumerate(plans):
+        assert np.array_equal(p.peaks(), ref[j]), j
+    with pytest.raises(_lib.GamsError):
+        plans[0].set_lane(4)
+    plans[1].set_lane(0)
+    plans[1].set_depth(3)
+    plans[1].run_n(30)
+    assert np.array_equal(plans[1].peaks(), ref[1])
+    for p in plans:
+        p.close()
+    for ss in sets:
+        ss.close()
+
+
+def test_guard_band_margin_on_small_inputs(eng, s288c):
+    """gams_wave_plan_set_guard: safety 1.0 (the derived bound with no factor on top) and all_exact (every
+    window in the reference's f32 order) give the oracle's signals, like the default 1.5."""
+    seqs = [bytes(s288c["I"]), bytes(s288c["Mito"]), synth(120000, 41).tobytes()]
+    ss = engine.SeqSet(eng, seqs)
+    plan = engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS | _lib.WAVE_DENSE)
+    total = plan.total_windows
+    exact = {}
+    for name, safety, all_exact in (("default", 1.5, False), ("safety1", 1.0, False), ("exact", 1.5, True),
+                                    ("wide", 50.0, False)):
+        plan.set_guard(safety, all_exact)
+        plan.run()
+        for c, s in enumerate(seqs):
+            ocnt, _, osig = ora.wave_windows(s, 100, 10, 100, 3.0, 1.0)
+            cnt, sig = plan.dense(c)
+            assert np.array_equal(cnt, ocnt) and np.array_equal(sig.astype(np.int32), osig), (name, c)
+        exact[name] = plan.exact_count()
+    assert exact["safety1"] <= exact["default"] <= exact["wide"] <= exact["exact"]
+    assert exact["default"] < 1e-3 * total
+    # every window that can signal (i >= lag, per ctg) went through the exact path, bar those the
+    # constant-count table settles (all lag counts and the window's own equal)
+    assert 0.98 * (total - 100 * len(seqs)) <= exact["exact"] <= total - 100 * len(seqs)
+    with pytest.raises(_lib.GamsError):
+        plan.set_guard(0.5, False)
+    plan.close()
+    ss.close()

@@ -21,6 +21,7 @@ tiles = [int(t) for t in args.tiles.split(",")]
 
 small = synth.genome_ctgs(synth.S288C_LENGTHS, 500000)
 big = synth.genome_ctgs(synth.SYNTH384_LENGTHS, 1000000, first_chr_index=500)
+atha = [synth.genome_ctgs(synth.ATHA_LENGTHS, 500000, first_chr_index=1 + 1000 * g) for g in range(3)]
 arms = []
 for path in args.libs:
     lib = _lib.bind(os.path.abspath(path), strict=False)
@@ -30,6 +31,21 @@ for path in args.libs:
         for tw in tiles:
             plan = engine.WavePlan(eng, ss, 100, args.step, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS, tile_windows=tw)
             arms.append(dict(lib=os.path.basename(path), wl=name, tw=tw, eng=eng, plan=plan, ss=ss, t=[]))
+    # three Atha-shaped genomes, launches rotate over them (every launch streams from HBM)
+    sets = [engine.SeqSet(eng, [c["seq"] for c in g]) for g in atha]
+    for tw in tiles:
+        plans = [engine.WavePlan(eng, ss, 100, args.step, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS, tile_windows=tw)
+                 for ss in sets]
+
+        class Rot:
+            def __init__(self, plans):
+                self.plans, self.i, self.total_windows = plans, 0, plans[0].total_windows
+
+            def run(self):
+                self.plans[self.i % 3].run()
+                self.i += 1
+
+        arms.append(dict(lib=os.path.basename(path), wl="Atha3", tw=tw, eng=eng, plan=Rot(plans), ss=sets, t=[]))
 for a in arms:
     for _ in range(3):
         a["plan"].run()
