@@ -26,6 +26,8 @@
 
 #include "common.hpp"
 
+#include <rocprim/rocprim.hpp>   // the one library primitive of this file: the segmented LSD radix sort
+
 #include <algorithm>
 #include <atomic>
 #include <numeric>
@@ -73,6 +75,9 @@ struct gams_index {
     IvRec *d_lrec = nullptr;         // the sorted pairs + the caller's index of each, 16 B (locate's scan)
     uint32_t *d_dir_start = nullptr; // m + n_groups entries: group g's directory begins at off[g] + g
     uint32_t *d_dir_stop = nullptr;
+    // everything above lives in one pooled HBM block
+    uint8_t *arena = nullptr;
+    size_t arena_bytes = 0;
 };
 
 struct gams_spans {
@@ -207,6 +212,101 @@ __global__ __launch_bounds__(256) void span_cover_kernel(const SpanGroup *groups
     out[q] = prop;
 }
 
+// ---- index build on the device (Lapper::new, src/libs/redis.rs:236-324) -----------------------
+// pack (start, stop) into one 64-bit key and number the intervals: a stable sort of the keys inside
+// every group is intervals.sort() of rust-lapper (ties keep the caller's order)
+__global__ __launch_bounds__(256) void index_pack_kernel(const uint32_t *starts, const uint32_t *stops, uint64_t m,
+                                                         uint64_t *key, uint32_t *val) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= m) return;
+    key[i] = ((uint64_t)starts[i] << 32) | stops[i];
+    val[i] = (uint32_t)i;
+}
+
+// sorted keys + permutation -> the ascending starts and the 16-B scan records
+__global__ __launch_bounds__(256) void index_unpack_kernel(const uint64_t *key, const uint32_t *perm, uint64_t m,
+                                                           uint32_t *lstart, IvRec *lrec) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= m) return;
+    const uint64_t k = key[i];
+    lstart[i] = (uint32_t)(k >> 32);
+    lrec[i] = IvRec{(uint32_t)(k >> 32), (uint32_t)k, (uint64_t)perm[i]};
+}
+
+__device__ __forceinline__ KeyDir dir_params(uint32_t first, uint32_t last, uint32_t n) {
+    KeyDir d{0u, 0u, 0u, 0u};
+    if (n == 0) return d;
+    d.key0 = first;
+    const uint32_t range = last - first;
+    while ((range >> d.shift) >= n) ++d.shift;     // (range >> shift) + 1 <= n buckets
+    d.nb = (range >> d.shift) + 1u;
+    return d;
+}
+
+// one wavefront per group: max(stop - start) (Lapper::max_len) and the directory headers
+__global__ __launch_bounds__(64) void index_group_kernel(const uint32_t *off32, uint32_t n_groups,
+                                                         const IvRec *lrec, const uint32_t *lstart,
+                                                         const uint32_t *stops_sorted, IndexGroup *groups) {
+    const uint32_t g = blockIdx.x;
+    if (g >= n_groups) return;
+    const uint32_t lo = off32[g], hi = off32[g + 1], n = hi - lo;
+    uint32_t ml = 0;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 64u) {
+        const IvRec r = lrec[i];
+        if (r.stop > r.start) ml = max(ml, r.stop - r.start);
+    }
+    for (int d = 32; d; d >>= 1) ml = max(ml, (uint32_t)__shfl_xor((int)ml, d, 64));
+    if (threadIdx.x == 0) {
+        IndexGroup G;
+        G.off = lo;
+        G.n = n;
+        G.maxlen = ml;
+        G.start = n ? dir_params(lstart[lo], lstart[hi - 1], n) : KeyDir{0u, 0u, 0u, 0u};
+        G.stop = n ? dir_params(stops_sorted[lo], stops_sorted[hi - 1], n) : KeyDir{0u, 0u, 0u, 0u};
+        groups[g] = G;
+    }
+}
+
+// bucket directories: slot j of the directory array belongs to the group g with off[g] + g <= j
+// (its bucket b = j - off[g] - g); dir[b] = rank of the first key >= key0 + (b << shift), dir[nb] = n
+__global__ __launch_bounds__(256) void index_dir_kernel(const uint32_t *off32, uint32_t n_groups, uint64_t slots,
+                                                        const IndexGroup *groups, const uint32_t *lstart,
+                                                        const uint32_t *stops_sorted, uint32_t *dir_start,
+                                                        uint32_t *dir_stop) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (j >= slots) return;
+    uint32_t lo = 0, hi = n_groups;                 // last group with off[g] + g <= j
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((uint64_t)off32[mid] + mid <= j)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint32_t g = lo;
+    const IndexGroup G = groups[g];
+    const uint32_t b = (uint32_t)(j - ((uint64_t)off32[g] + g));
+    auto fill = [&](const uint32_t *keys, const KeyDir d, uint32_t *dir) {
+        if (b > d.nb || (G.n == 0 && b > 0)) return;
+        uint32_t r = G.n;
+        if (b < d.nb) {
+            const uint64_t edge = (uint64_t)d.key0 + ((uint64_t)b << d.shift);
+            uint32_t a = 0, z = G.n;
+            while (a < z) {
+                const uint32_t mid = a + ((z - a) >> 1);
+                if ((uint64_t)keys[G.off + mid] < edge)
+                    a = mid + 1;
+                else
+                    z = mid;
+            }
+            r = a;
+        }
+        dir[j] = G.n == 0 ? 0u : r;
+    };
+    fill(lstart, G.start, dir_start);
+    fill(stops_sorted, G.stop, dir_stop);
+}
+
 // Host side of the directory: keys[0..n) ascending (already biased); dir gets nb+1 <= n+1 entries.
 KeyDir build_dir(const uint32_t *keys, uint32_t n, uint32_t *dir) {
     KeyDir d{0u, 0u, 0u, 0u};
@@ -253,17 +353,21 @@ hipError_t to_device(T **d, const T *hsrc, size_t n) {
     return e;
 }
 
-// scratch device copies of the query columns + result column
+// scratch device copies of the query columns + result column: pooled HBM blocks of the handle
+// (a hipMalloc / hipFree pair per column and call cost more than the kernel)
 struct QueryBuf {
-    std::vector<void *> ptrs;
+    gams_gpu_t *h;
+    std::vector<std::pair<void *, size_t>> blocks;
+    explicit QueryBuf(gams_gpu_t *handle) : h(handle) {}
     ~QueryBuf() {
-        for (void *p : ptrs) (void)hipFree(p);
+        for (auto &b : blocks) gams_pool_free(h, false, b.first, b.second);
     }
     template <typename T>
     hipError_t in(T **d, const T *hsrc, uint64_t n, hipStream_t st) {
-        hipError_t e = hipMalloc(d, std::max<uint64_t>(n, 1) * sizeof(T));
+        size_t cap = 0;
+        hipError_t e = gams_pool_alloc(h, false, std::max<uint64_t>(n, 1) * sizeof(T), reinterpret_cast<void **>(d), &cap);
         if (e != hipSuccess) return e;
-        ptrs.push_back(*d);
+        blocks.emplace_back(*d, cap);
         if (n && hsrc) e = hipMemcpyAsync(*d, hsrc, n * sizeof(T), hipMemcpyHostToDevice, st);
         return e;
     }
@@ -280,51 +384,107 @@ int gams_index_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
     if (m && (!starts || !stops)) return gams_fail(h, GAMS_EINVAL, "index_create: null interval arrays");
     for (uint32_t g = 0; g < n_groups; ++g)
         if (group_off[g] > group_off[g + 1]) return gams_fail(h, GAMS_EINVAL, "index_create: group_off not ascending");
-    for (uint32_t g = 0; g < n_groups; ++g)
-        if (group_off[g + 1] - group_off[g] > 0xfffffff0ull)
-            return gams_fail(h, GAMS_EUNSUPPORTED, "index_create: a group holds more than 2^32-16 intervals");
+    if (m > 0xfffffff0ull)
+        return gams_fail(h, GAMS_EUNSUPPORTED, "index_create: more than 2^32-16 intervals in one index");
     GAMS_HIP(h, hipSetDevice(h->device));
-    // Lapper::new: intervals.sort() by (start, stop); stops also sorted on their own
-    std::vector<uint32_t> tt(stops, stops + m), ls(m);
-    std::vector<IvRec> lrec(m);
-    std::vector<uint32_t> dir_s(m + n_groups + 1), dir_t(m + n_groups + 1);
-    std::vector<uint64_t> perm(m);
-    std::vector<IndexGroup> groups(std::max<uint32_t>(n_groups, 1));
-    std::iota(perm.begin(), perm.end(), 0ull);
-    for_groups(n_groups, [&](uint32_t g) {
-        const uint64_t lo = group_off[g], hi = group_off[g + 1];
-        std::sort(tt.begin() + lo, tt.begin() + hi);
-        std::stable_sort(perm.begin() + lo, perm.begin() + hi, [&](uint64_t a, uint64_t b) {
-            return starts[a] != starts[b] ? starts[a] < starts[b] : stops[a] < stops[b];
-        });
-        uint32_t ml = 0;
-        for (uint64_t i = lo; i < hi; ++i) {
-            ls[i] = starts[perm[i]];
-            lrec[i] = IvRec{ls[i], stops[perm[i]], perm[i]};
-            if (lrec[i].stop > ls[i]) ml = std::max(ml, lrec[i].stop - ls[i]);
-        }
-        IndexGroup &G = groups[g];
-        G.off = lo;
-        G.n = (uint32_t)(hi - lo);
-        G.maxlen = ml;
-        G.start = build_dir(ls.data() + lo, G.n, dir_s.data() + lo + g);
-        G.stop = build_dir(tt.data() + lo, G.n, dir_t.data() + lo + g);
-    });
+    // Lapper::new on the device: intervals.sort() by (start, stop) inside every group = a stable
+    // segmented radix sort of the packed 64-bit keys; the stops are also sorted on their own.  The
+    // bucket directories and Lapper::max_len come from three small kernels over the sorted arrays.
+    const uint32_t ng1 = std::max<uint32_t>(n_groups, 1);
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_groups = al((size_t)ng1 * sizeof(IndexGroup)), b_u32 = al(std::max<uint64_t>(m, 1) * 4),
+                 b_rec = al(std::max<uint64_t>(m, 1) * sizeof(IvRec)), b_dir = al((m + n_groups + 1) * 4);
     gams_index_t *ix = new gams_index_t();
     ix->n_groups = n_groups;
     ix->m = m;
-    hipError_t e = to_device(&ix->d_groups, groups.data(), groups.size());
-    if (e == hipSuccess) e = to_device(&ix->d_stops, tt.data(), m);
-    if (e == hipSuccess) e = to_device(&ix->d_lstart, ls.data(), m);
-    if (e == hipSuccess) e = to_device(&ix->d_lrec, lrec.data(), m);
-    if (e == hipSuccess) e = to_device(&ix->d_dir_start, dir_s.data(), dir_s.size());
-    if (e == hipSuccess) e = to_device(&ix->d_dir_stop, dir_t.data(), dir_t.size());
-    if (e != hipSuccess) {
-        (void)hipGetLastError();   // reported below, not left sticky
+    hipError_t e = gams_pool_alloc(h, false, b_groups + 2 * b_u32 + b_rec + 2 * b_dir,
+                                   reinterpret_cast<void **>(&ix->arena), &ix->arena_bytes);
+    // scratch: raw columns, packed keys in/out, permutation in/out, 32-bit offsets, radix-sort storage
+    const size_t b_key = al(std::max<uint64_t>(m, 1) * 8), b_off = al(((size_t)n_groups + 1) * 4);
+    uint8_t *scratch = nullptr;
+    size_t scratch_bytes = 0, tmp_bytes_pairs = 0, tmp_bytes_keys = 0;
+    uint8_t *d_tmp = nullptr;
+    size_t d_tmp_bytes = 0;
+    auto fail = [&](hipError_t err, const char *what) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(h->compute);
+        gams_pool_free(h, false, scratch, scratch_bytes);
+        gams_pool_free(h, false, d_tmp, d_tmp_bytes);
         gams_index_destroy(h, ix);
-        return gams_fail(h, e == hipErrorOutOfMemory ? GAMS_ENOMEM : GAMS_EHIP,
-                         std::string("index_create: ") + hipGetErrorString(e));
+        return gams_fail(h, err == hipErrorOutOfMemory ? GAMS_ENOMEM : GAMS_EHIP,
+                         std::string("index_create: ") + what + ": " + hipGetErrorString(err));
+    };
+    if (e != hipSuccess) return fail(e, "hipMalloc(index)");
+    {
+        uint8_t *p = ix->arena;
+        ix->d_groups = reinterpret_cast<IndexGroup *>(p);
+        p += b_groups;
+        ix->d_stops = reinterpret_cast<uint32_t *>(p);
+        p += b_u32;
+        ix->d_lstart = reinterpret_cast<uint32_t *>(p);
+        p += b_u32;
+        ix->d_lrec = reinterpret_cast<IvRec *>(p);
+        p += b_rec;
+        ix->d_dir_start = reinterpret_cast<uint32_t *>(p);
+        p += b_dir;
+        ix->d_dir_stop = reinterpret_cast<uint32_t *>(p);
     }
+    e = gams_pool_alloc(h, false, 2 * b_u32 + 2 * b_key + 2 * b_u32 + b_off, reinterpret_cast<void **>(&scratch),
+                        &scratch_bytes);
+    if (e != hipSuccess) return fail(e, "hipMalloc(scratch)");
+    uint32_t *d_starts_in = reinterpret_cast<uint32_t *>(scratch);
+    uint32_t *d_stops_in = reinterpret_cast<uint32_t *>(scratch + b_u32);
+    uint64_t *d_key_in = reinterpret_cast<uint64_t *>(scratch + 2 * b_u32);
+    uint64_t *d_key_out = reinterpret_cast<uint64_t *>(scratch + 2 * b_u32 + b_key);
+    uint32_t *d_val_in = reinterpret_cast<uint32_t *>(scratch + 2 * b_u32 + 2 * b_key);
+    uint32_t *d_val_out = reinterpret_cast<uint32_t *>(scratch + 3 * b_u32 + 2 * b_key);
+    uint32_t *d_off32 = reinterpret_cast<uint32_t *>(scratch + 4 * b_u32 + 2 * b_key);
+    hipStream_t st = h->compute;
+    std::vector<uint32_t> off32((size_t)n_groups + 1);
+    for (uint32_t g = 0; g <= n_groups; ++g) off32[g] = (uint32_t)group_off[g];
+    if ((e = hipMemcpyAsync(d_off32, off32.data(), off32.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess)
+        return fail(e, "copy offsets");
+    if (m) {
+        if ((e = hipMemcpyAsync(d_starts_in, starts, m * 4, hipMemcpyHostToDevice, st)) != hipSuccess)
+            return fail(e, "copy starts");
+        if ((e = hipMemcpyAsync(d_stops_in, stops, m * 4, hipMemcpyHostToDevice, st)) != hipSuccess)
+            return fail(e, "copy stops");
+        const unsigned blocks = (unsigned)((m + 255) / 256);
+        hipLaunchKernelGGL(index_pack_kernel, dim3(blocks), dim3(256), 0, st, d_starts_in, d_stops_in, m, d_key_in,
+                           d_val_in);
+        if ((e = hipGetLastError()) != hipSuccess) return fail(e, "pack");
+        e = rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes_pairs, d_key_in, d_key_out, d_val_in, d_val_out,
+                                                (unsigned)m, n_groups, d_off32, d_off32 + 1, 0, 64, st);
+        if (e != hipSuccess) return fail(e, "radix sort (size query)");
+        e = rocprim::segmented_radix_sort_keys(nullptr, tmp_bytes_keys, d_stops_in, ix->d_stops, (unsigned)m, n_groups,
+                                               d_off32, d_off32 + 1, 0, 32, st);
+        if (e != hipSuccess) return fail(e, "radix sort (size query)");
+        e = gams_pool_alloc(h, false, std::max<size_t>(std::max(tmp_bytes_pairs, tmp_bytes_keys), 256),
+                            reinterpret_cast<void **>(&d_tmp), &d_tmp_bytes);
+        if (e != hipSuccess) return fail(e, "hipMalloc(sort storage)");
+        e = rocprim::segmented_radix_sort_pairs(d_tmp, tmp_bytes_pairs, d_key_in, d_key_out, d_val_in, d_val_out,
+                                                (unsigned)m, n_groups, d_off32, d_off32 + 1, 0, 64, st);
+        if (e != hipSuccess) return fail(e, "radix sort of (start, stop)");
+        e = rocprim::segmented_radix_sort_keys(d_tmp, tmp_bytes_keys, d_stops_in, ix->d_stops, (unsigned)m, n_groups,
+                                               d_off32, d_off32 + 1, 0, 32, st);
+        if (e != hipSuccess) return fail(e, "radix sort of stops");
+        hipLaunchKernelGGL(index_unpack_kernel, dim3(blocks), dim3(256), 0, st, d_key_out, d_val_out, m, ix->d_lstart,
+                           ix->d_lrec);
+        if ((e = hipGetLastError()) != hipSuccess) return fail(e, "unpack");
+    }
+    if (n_groups) {
+        hipLaunchKernelGGL(index_group_kernel, dim3(n_groups), dim3(64), 0, st, d_off32, n_groups, ix->d_lrec,
+                           ix->d_lstart, ix->d_stops, ix->d_groups);
+        if ((e = hipGetLastError()) != hipSuccess) return fail(e, "group records");
+        const uint64_t slots = m + n_groups;        // the last group's directory ends at m + n_groups (inclusive slot)
+        hipLaunchKernelGGL(index_dir_kernel, dim3((unsigned)((slots + 1 + 255) / 256)), dim3(256), 0, st, d_off32,
+                           n_groups, slots + 1, ix->d_groups, ix->d_lstart, ix->d_stops, ix->d_dir_start,
+                           ix->d_dir_stop);
+        if ((e = hipGetLastError()) != hipSuccess) return fail(e, "directories");
+    }
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "index build");
+    gams_pool_free(h, false, scratch, scratch_bytes);
+    gams_pool_free(h, false, d_tmp, d_tmp_bytes);
     *out = ix;
     return GAMS_OK;
 }
@@ -335,12 +495,7 @@ void gams_index_destroy(gams_gpu_t *h, gams_index_t *ix) {
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->compute);
     }
-    (void)hipFree(ix->d_groups);
-    (void)hipFree(ix->d_stops);
-    (void)hipFree(ix->d_lstart);
-    (void)hipFree(ix->d_lrec);
-    (void)hipFree(ix->d_dir_start);
-    (void)hipFree(ix->d_dir_stop);
+    gams_pool_free(h, false, ix->arena, ix->arena_bytes);
     delete ix;
 }
 
@@ -358,7 +513,7 @@ int gams_gpu_count(gams_gpu_t *h, gams_index_t *ix, const uint32_t *group, const
     if (nq == 0) return GAMS_OK;
     if ((nq + 255) / 256 > 0x7fffffffull) return gams_fail(h, GAMS_EUNSUPPORTED, "gpu_count: too many queries");
     GAMS_HIP(h, hipSetDevice(h->device));
-    QueryBuf qb;
+    QueryBuf qb(h);
     uint32_t *d_g, *d_s, *d_e;
     int32_t *d_o;
     Q_HIP(qb.in(&d_g, group, nq, h->compute));
@@ -384,7 +539,7 @@ int gams_gpu_locate(gams_gpu_t *h, gams_index_t *ix, const uint32_t *group, cons
     if (nq == 0) return GAMS_OK;
     if ((nq + 255) / 256 > 0x7fffffffull) return gams_fail(h, GAMS_EUNSUPPORTED, "gpu_locate: too many queries");
     GAMS_HIP(h, hipSetDevice(h->device));
-    QueryBuf qb;
+    QueryBuf qb(h);
     uint32_t *d_g, *d_s, *d_e;
     int64_t *d_o;
     Q_HIP(qb.in(&d_g, group, nq, h->compute));
@@ -468,7 +623,7 @@ int gams_gpu_cover(gams_gpu_t *h, gams_spans_t *sp, const uint32_t *group, const
     if (nq == 0) return GAMS_OK;
     if ((nq + 255) / 256 > 0x7fffffffull) return gams_fail(h, GAMS_EUNSUPPORTED, "gpu_cover: too many queries");
     GAMS_HIP(h, hipSetDevice(h->device));
-    QueryBuf qb;
+    QueryBuf qb(h);
     uint32_t *d_g;
     int32_t *d_cl, *d_ch, *d_s, *d_e;
     float *d_o;

@@ -122,3 +122,67 @@ def test_guard_band_margin_on_the_atha_genome(eng):
     p2.close()
     s2.close()
     ss.close()
+
+
+def test_config2_sw_on_the_atha_genome(eng):
+    """BASELINE configs[2], the `fsw` leg (src/cmd_gams/sw.rs:141-184): 1e5 point features (SURVEY 8d C3,
+    seed+1) over the A. thaliana-shaped genome through the multi-handle host path.  Full text equality with
+    the oracle on the first chromosome's share (> 2.5e4 features, ~1e6 rows); on all features the
+    size-independent properties: per feature one M row then L1..Ln then R1..Rm, consecutive distances,
+    100-bp windows abutting, everything inside the ctg, gc fields rounded to 4 places in [0, 1]."""
+    from gams_amd import host
+
+    ctgs = synth.genome_ctgs(synth.ATHA_LENGTHS, 500000)
+    pos = synth.point_features(ctgs, 100000)
+    feats = [[(f"feature:{c['id']}:{i + 1}", int(p), int(p)) for i, p in enumerate(ps)] for c, ps in zip(ctgs, pos)]
+    n_feat = sum(len(f) for f in feats)
+    assert 99_000 < n_feat < 101_000
+    engines = [eng, engine.Engine(0)]
+    try:
+        text = host.sw_multi(engines, ctgs, feats)
+    finally:
+        engines[1].close()
+    rows = text.splitlines()
+    assert len(rows) > 40 * n_feat * 0.97                     # <= 41 rows per feature, fewer only at ctg edges
+    # ---- oracle text for chromosome 1 (the first ctgs) ----
+    first = [i for i, c in enumerate(ctgs) if c["chr_id"] == ctgs[0]["chr_id"]]
+    assert sum(len(feats[i]) for i in first) > 25_000
+    exp = "".join(ora.sw_proc_ctg(ctgs[i]["chr_id"], ctgs[i]["chr_start"], ctgs[i]["chr_end"], ctgs[i]["seq"], feats[i])
+                  for i in first if feats[i])
+    n_exp = exp.count("\n")
+    assert "\n".join(rows[:n_exp]) + "\n" == exp
+    # ---- properties on every row ----
+    by_ctg = {c["id"]: c for c in ctgs}
+    cur, seen_feat, expect_sn = None, 0, 0
+    prev_type, prev_dist, prev_range = None, 0, None
+    for r in rows:
+        f = r.split("\t")
+        assert len(f) == 9
+        sid, rg, typ, dist = f[0], f[1], f[2], int(f[3])
+        fid, sn = sid[3:].rsplit(":", 1)
+        chr_id, se = rg.split(":")
+        s, e = (int(x) for x in se.split("-"))
+        ctg = by_ctg[fid.split(":", 1)[1].rsplit(":", 1)[0]]
+        assert ctg["chr_start"] <= s <= e <= ctg["chr_end"] and chr_id == ctg["chr_id"]
+        if fid != cur:
+            cur, seen_feat, expect_sn = fid, seen_feat + 1, 1
+            assert typ == "M" and dist == 0
+            assert e - s + 1 in (99, 100) or ctg["chr_start"] == s or ctg["chr_end"] == e   # clipped at a ctg edge
+            m_range = (s, e)
+        else:
+            assert typ in ("L", "R") and e - s + 1 == 100
+            if typ == prev_type:
+                assert dist == prev_dist + 1
+                assert (e + 1 == prev_range[0]) if typ == "L" else (s == prev_range[1] + 1)
+            else:
+                assert dist == 1 and (prev_type, typ) in (("M", "L"), ("M", "R"), ("L", "R"))
+                assert (e + 1 == m_range[0]) if typ == "L" else (s == m_range[1] + 1)
+        assert int(sn) == expect_sn
+        expect_sn += 1
+        prev_type, prev_dist, prev_range = typ, dist, (s, e)
+        assert f[8] == ""                                     # rg_count: declared, never filled (sw.rs:167)
+        for k, v in enumerate(f[4:8]):
+            x = float(v)
+            assert x != x or (0.0 <= x <= 1.0) or (k == 3 and x >= 0.0)   # cv = stddev / mean may exceed 1
+            assert len(v.split(".")[-1]) <= 4 or "e" in v               # round(.., 4), Rust {} formatting
+    assert seen_feat == n_feat
