@@ -1,0 +1,127 @@
+"""BASELINE configs[4] cut to one GPU of eight (32 Gb of coordinates, 1e8 stored `rg`,
+1e8 queries, 1e6 spans per chromosome -> 4 chromosomes, 4,000 ctgs, 1.25e7 stored point ranges,
+1.25e7 queries, 4e6 spans): `locate --count`, `locate` and `anno` through the C ABI.
+Expected values: closed forms in numpy (searchsorted over composite group|key columns) for EVERY
+query, and the oracle's rust-lapper / anno restatement (src/libs/utils.rs:7-36,
+src/cmd_gams/anno.rs:128-139) on a sample."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gams_amd import engine, synth
+from oracle import oracle as ora
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = engine.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def c5():
+    return synth.c5_workload(share=8)
+
+
+def test_c5_locate_count(eng, c5):
+    w = c5
+    nq = w["q_start"].size
+    assert w["n_ctg"] == 4000 and nq == 12_500_000 and w["rg_start"].size == 12_500_000
+    ix = C.c_void_p()
+    eng.check(eng.lib.gams_index_create(eng.h, w["n_ctg"], w["rg_off"].ctypes.data, w["rg_start"].ctypes.data,
+                                        w["rg_stop"].ctypes.data, C.byref(ix)))
+    cnt = np.full(nq, -1, np.int32)
+    # the reference passes (rg.start, rg.end) to Lapper::count: the end is exclusive (utils.rs:35)
+    eng.check(eng.lib.gams_gpu_count(eng.h, ix, w["q_ctg"].ctypes.data, w["q_start"].ctypes.data,
+                                     w["q_end"].ctypes.data, nq, cnt.ctypes.data))
+    eng.lib.gams_index_destroy(eng.h, ix)
+    g = np.repeat(np.arange(w["n_ctg"], dtype=np.uint64), np.diff(w["rg_off"]).astype(np.int64))
+    comp_s = np.sort((g << np.uint64(32)) | w["rg_start"].astype(np.uint64))
+    comp_t = np.sort((g << np.uint64(32)) | w["rg_stop"].astype(np.uint64))
+    qg = w["q_ctg"].astype(np.uint64) << np.uint64(32)
+    last = np.searchsorted(comp_s, qg | w["q_end"].astype(np.uint64), "left")
+    first = np.searchsorted(comp_t, qg | (w["q_start"].astype(np.uint64) + np.uint64(1)), "left")
+    exp = last.astype(np.int64) - first.astype(np.int64)
+    # a query whose start sits in the last 2 kb of a ctg keeps its ctg's group: only that group's points count
+    assert np.array_equal(cnt.astype(np.int64), exp)
+    assert 0 < cnt.max() < 40 and (cnt > 0).mean() > 0.5          # ~3 stored points per 1000 bp of query
+    rng = np.random.default_rng(1)
+    for q in rng.integers(0, nq, 300):
+        c = int(w["q_ctg"][q])
+        lo, hi = int(w["rg_off"][c]), int(w["rg_off"][c + 1])
+        assert cnt[q] == ora.lapper_count(np.sort(w["rg_start"][lo:hi]), np.sort(w["rg_stop"][lo:hi]),
+                                          int(w["q_start"][q]), int(w["q_end"][q]))
+
+
+def test_c5_locate_ctg(eng, c5):
+    w = c5
+    nq = w["q_start"].size
+    ix = C.c_void_p()
+    eng.check(eng.lib.gams_index_create(eng.h, w["n_chr"], w["ctg_off"].ctypes.data, w["ctg_start"].ctypes.data,
+                                        w["ctg_stop"].ctypes.data, C.byref(ix)))
+    hit = np.full(nq, -7, np.int64)
+    eng.check(eng.lib.gams_gpu_locate(eng.h, ix, w["q_chr"].ctypes.data, w["q_start"].ctypes.data,
+                                      w["q_end"].ctypes.data, nq, hit.ctypes.data))
+    eng.lib.gams_index_destroy(eng.h, ix)
+    # ctgs tile the chromosome: the ctg holding q_start is the first overlap unless the half-open query
+    # [start, end) is empty on it (a point range exactly on ctg.chr_start: SURVEY 8a-16)
+    k0 = (w["q_start"].astype(np.int64) - 1) // w["piece"]
+    ok = k0 * w["piece"] + 1 < w["q_end"].astype(np.int64)
+    exp = np.where(ok, w["q_chr"].astype(np.int64) * w["per_chr"] + k0, -1)
+    assert np.array_equal(hit, exp)
+    assert np.array_equal(exp[ok], w["q_ctg"][ok].astype(np.int64))
+    rng = np.random.default_rng(2)
+    pick = np.concatenate([rng.integers(0, nq, 200), np.flatnonzero(~ok)[:50]])
+    for q in pick:
+        c = int(w["q_chr"][q])
+        lo, hi = int(w["ctg_off"][c]), int(w["ctg_off"][c + 1])
+        k = ora.lapper_find_first(w["ctg_start"][lo:hi], w["ctg_stop"][lo:hi], int(w["q_start"][q]), int(w["q_end"][q]))
+        assert hit[q] == (lo + k if k >= 0 else -1)
+
+
+def test_c5_anno(eng, c5):
+    w = c5
+    nq = w["q_start"].size
+    sp = C.c_void_p()
+    eng.check(eng.lib.gams_spans_create(eng.h, w["n_chr"], w["sp_off"].ctypes.data, w["sp_lo"].ctypes.data,
+                                        w["sp_hi"].ctypes.data, C.byref(sp)))
+    s = w["q_start"].astype(np.int32)
+    e = w["q_end"].astype(np.int32)
+    cl = (((s.astype(np.int64) - 1) // w["piece"]) * w["piece"] + 1).astype(np.int32)     # the ctg of q_start
+    ch = (cl + (w["piece"] - 1)).astype(np.int32)
+    prop = np.full(nq, -1.0, np.float32)
+    eng.check(eng.lib.gams_gpu_cover(eng.h, sp, w["q_chr"].ctypes.data, cl.ctypes.data, ch.ctypes.data,
+                                     s.ctypes.data, e.ctypes.data, nq, prop.ctypes.data))
+    eng.lib.gams_spans_destroy(eng.h, sp)
+    # closed form: covered(x) = bases of the chromosome's spans at positions <= x
+    n_sp = int(w["sp_off"][1])
+    lo = w["sp_lo"].astype(np.int64)
+    hi = w["sp_hi"].astype(np.int64)
+    chr_of = np.repeat(np.arange(w["n_chr"], dtype=np.int64), n_sp)
+    comp_lo = (chr_of << 32) | lo
+    cum = np.concatenate([[0], np.cumsum(hi - lo + 1)])
+
+    def covered(c, x):
+        i = np.searchsorted(comp_lo, (c << 32) | x, "right")            # spans with lo <= x (all earlier chrs too)
+        base = cum[i]                                                   # all of them, whole
+        last = np.maximum(i - 1, 0)
+        over = np.where((i > 0) & (chr_of[last] == c), np.maximum(hi[last] - x, 0), 0)
+        return base - over
+
+    c = w["q_chr"].astype(np.int64)
+    L = np.maximum(s.astype(np.int64), cl)
+    H = np.minimum(e.astype(np.int64), ch)
+    card = np.where(H >= L, covered(c, H) - covered(c, L - 1), 0)
+    exp = (card.astype(np.int32).astype(np.float32) / (e.astype(np.int64) - s + 1).astype(np.int32).astype(np.float32))
+    assert np.array_equal(prop, exp)
+    assert 0.3 < float(prop.mean()) < 0.7                                # half of every chromosome is covered
+    rng = np.random.default_rng(3)
+    for q in rng.integers(0, nq, 200):
+        k = int(w["q_chr"][q])
+        a, b = int(w["sp_off"][k]), int(w["sp_off"][k + 1])
+        got = ora.anno_prop(w["sp_lo"][a:b], w["sp_hi"][a:b], int(cl[q]), int(ch[q]), int(s[q]), int(e[q]))
+        assert np.float32(got) == prop[q]
