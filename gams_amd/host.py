@@ -65,6 +65,23 @@ def load():
     L.gams_host_sw_multi.restype = C.c_void_p
     L.gams_host_sw_multi.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, sp, sp, ip, ip, C.c_void_p, C.c_char_p,
                                      C.c_int32, C.c_int32, C.c_int32]
+    u64p = C.POINTER(C.c_uint64)
+    L.gams_host_bincode_ctg_bundle.restype = C.c_void_p
+    L.gams_host_bincode_ctg_bundle.argtypes = [C.c_uint32, sp, sp, ip, ip, u64p]
+    L.gams_host_bincode_ctg_bundle_decode.restype = C.c_void_p
+    L.gams_host_bincode_ctg_bundle_decode.argtypes = [C.c_void_p, C.c_uint64]
+    L.gams_host_bincode_lapper.restype = C.c_void_p
+    L.gams_host_bincode_lapper.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, sp, u64p]
+    L.gams_host_bincode_lapper_decode.restype = C.c_void_p
+    L.gams_host_bincode_lapper_decode.argtypes = [C.c_void_p, C.c_uint64]
+    L.gams_host_resp_command.restype = C.c_void_p
+    L.gams_host_resp_command.argtypes = [C.c_uint32, sp, u64p, u64p]
+    L.gams_host_resp_scan_values.restype = C.c_void_p
+    L.gams_host_resp_scan_values.argtypes = [C.c_char_p, u64p]
+    L.gams_host_resp_parse.restype = C.c_void_p
+    L.gams_host_resp_parse.argtypes = [C.c_char_p, C.c_uint64, u64p]
+    L.gams_host_index_from_lappers.restype = C.c_void_p
+    L.gams_host_index_from_lappers.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_char_p), u64p]
     L.gams_host_header.restype = C.c_void_p
     L.gams_host_header.argtypes = [C.c_int]
     L.gams_host_tsv_ctgs.restype = C.c_void_p
@@ -308,3 +325,73 @@ def fmt_f32(v):
 
 def range_roundtrip(s):
     return _take(load().gams_host_range_roundtrip(s.encode()))
+
+
+# ---- wire formats either side of the path (gams_wire.cpp; SURVEY 8 f-3, parity unpinned) --------
+def _take_bytes(p, n):
+    if not p:
+        raise HostError(load().gams_host_last_code(), load().gams_host_last_error().decode(errors="replace"))
+    out = C.string_at(p, n.value)
+    load().gams_host_free(p)
+    return out
+
+
+def bincode_ctg_bundle(ctgs):
+    """bundle:ctg:{chr}: bincode 1.3.3 of BTreeMap<String, Ctg> (redis.rs:216-233)"""
+    n, ids, chrs, st, en = _ctg_arrays(ctgs)
+    ln = C.c_uint64()
+    return _take_bytes(load().gams_host_bincode_ctg_bundle(n, ids, chrs, st.ctypes.data, en.ctypes.data, C.byref(ln)), ln)
+
+
+def bincode_ctg_bundle_decode(blob):
+    """-> the ctg.tsv text of the decoded map"""
+    return _take(load().gams_host_bincode_ctg_bundle_decode(blob, len(blob)))
+
+
+def bincode_lapper(starts, stops, vals=None):
+    """idx:ctg:{chr} / idx:rg:{ctg}: Lapper::new(ivs) serialised (redis.rs:236-324)"""
+    a = np.ascontiguousarray(starts, np.uint32)
+    b = np.ascontiguousarray(stops, np.uint32)
+    vp = None
+    if vals is not None:
+        vp = (C.c_char_p * max(len(vals), 1))(*[v.encode() for v in vals])
+    ln = C.c_uint64()
+    return _take_bytes(load().gams_host_bincode_lapper(a.size, a.ctypes.data, b.ctypes.data, vp, C.byref(ln)), ln)
+
+
+def bincode_lapper_decode(blob):
+    return _take(load().gams_host_bincode_lapper_decode(blob, len(blob)))
+
+
+def resp_command(args):
+    raw = [a if isinstance(a, bytes) else str(a).encode() for a in args]
+    ptrs = (C.c_char_p * max(len(raw), 1))(*raw)
+    lens = (C.c_uint64 * max(len(raw), 1))(*[len(a) for a in raw])
+    ln = C.c_uint64()
+    return _take_bytes(load().gams_host_resp_command(len(raw), ptrs, lens, C.byref(ln)), ln)
+
+
+def resp_scan_values(pattern):
+    ln = C.c_uint64()
+    return _take_bytes(load().gams_host_resp_scan_values(pattern.encode(), C.byref(ln)), ln)
+
+
+def resp_parse(buf):
+    """-> (flat text of the first reply in buf, bytes consumed); consumed == 0: the reply is incomplete"""
+    used = C.c_uint64()
+    p = load().gams_host_resp_parse(buf, len(buf), C.byref(used))
+    if not p:
+        raise HostError(load().gams_host_last_code(), load().gams_host_last_error().decode(errors="replace"))
+    out = C.string_at(p).decode(errors="replace")
+    load().gams_host_free(p)
+    return out, used.value
+
+
+def index_from_lappers(eng, blobs):
+    """device index (gams_index_t*, as c_void_p) over idx: blobs, one group per blob; free with gams_index_destroy"""
+    ptrs = (C.c_char_p * max(len(blobs), 1))(*blobs)
+    lens = (C.c_uint64 * max(len(blobs), 1))(*[len(b) for b in blobs])
+    p = load().gams_host_index_from_lappers(eng.h, len(blobs), ptrs, lens)
+    if not p:
+        raise HostError(load().gams_host_last_code(), load().gams_host_last_error().decode(errors="replace"))
+    return C.c_void_p(p)

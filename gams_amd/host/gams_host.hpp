@@ -201,4 +201,41 @@ std::string anno(gams_gpu_t *h, const std::map<std::string, Runlist> &sets, cons
                  const std::vector<std::string> &lines, bool header, const std::string &prefix, size_t idx_id,
                  size_t idx_range);
 
+// ---- wire formats either side of the path (gams_wire.cpp; SURVEY 8 f-3, parity unpinned) ----------
+namespace wire {
+// bundle:ctg:{chr}: bincode 1.3.3 of BTreeMap<String, Ctg> (redis.rs:216-233)
+std::string bincode_ctg_bundle(const std::vector<Ctg> &ctgs);
+std::vector<Ctg> bincode_ctg_bundle_decode(const uint8_t *bytes, size_t n);
+// idx:ctg:{chr} / idx:rg:{ctg}: bincode of rust-lapper's Lapper<u32, String> (redis.rs:236-324)
+struct LapperIv {
+    uint32_t start = 0, stop = 0;   // half-open, stop = end + 1 (redis.rs:245-248, 291-294)
+    std::string val;                // ctg id for idx:ctg, "" for idx:rg
+};
+struct LapperBlob {
+    std::vector<LapperIv> intervals;      // sorted by (start, stop)
+    std::vector<uint32_t> starts, stops;  // each sorted on its own
+    uint32_t max_len = 0, cov = 0;
+    bool has_cov = false, overlaps_merged = false;
+};
+std::string bincode_lapper(const std::vector<LapperIv> &intervals);   // Lapper::new + serialize
+LapperBlob bincode_lapper_decode(const uint8_t *bytes, size_t n);
+// device index over decoded idx: blobs, one group per blob (caller destroys it with gams_index_destroy)
+gams_index_t *index_from_lappers(gams_gpu_t *h, const std::vector<LapperBlob> &blobs);
+// RESP2
+struct RespValue {
+    enum Type { Simple, Error, Integer, Bulk, Null, Array } type = Null;
+    std::string str;
+    int64_t integer = 0;
+    std::vector<RespValue> array;
+};
+std::string resp_command(const std::vector<std::string> &args);
+std::string resp_pipeline_set(const std::vector<std::pair<std::string, std::string>> &kv);
+std::string resp_eval(const std::string &script, const std::vector<std::string> &keys,
+                      const std::vector<std::string> &argv);
+const char *scan_values_script();
+// one reply from the front of `bytes`: returns the bytes consumed, 0 if the reply is not complete yet
+size_t resp_parse(const char *bytes, size_t n, RespValue &out);
+std::string resp_dump(const RespValue &v);
+}  // namespace wire
+
 }  // namespace gams

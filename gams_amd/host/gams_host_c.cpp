@@ -33,6 +33,32 @@ char *guarded(F &&f) {
     return nullptr;
 }
 
+char *dup_bytes(const std::string &s, uint64_t *out_len) {
+    if (out_len) *out_len = s.size();
+    char *p = (char *)std::malloc(s.size() + 1);
+    if (p) {
+        std::memcpy(p, s.data(), s.size());
+        p[s.size()] = 0;
+    }
+    return p;
+}
+template <typename F>
+char *guarded_bytes(uint64_t *out_len, F &&f) {
+    try {
+        g_err.clear();
+        g_code = 0;
+        return dup_bytes(f(), out_len);
+    } catch (const gams::Error &e) {
+        g_err = e.what();
+        g_code = e.code;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        g_code = -1;
+    }
+    return nullptr;
+}
+
+
 std::vector<gams::Ctg> make_ctgs(uint32_t n, const char *const *ids, const char *const *chrs, const int32_t *starts,
                                  const int32_t *ends) {
     std::vector<gams::Ctg> v(n);
@@ -384,4 +410,82 @@ char *gams_host_range_roundtrip(const char *s) {
     return dup(r.valid ? r.to_string() : std::string("<invalid>"));
 }
 
+
+// ---- wire formats (gams_wire.cpp): byte strings out, *out_len = their length ------------------------
+char *gams_host_bincode_ctg_bundle(uint32_t n, const char *const *ids, const char *const *chrs, const int32_t *starts,
+                                   const int32_t *ends, uint64_t *out_len) {
+    return guarded_bytes(out_len, [&] { return gams::wire::bincode_ctg_bundle(make_ctgs(n, ids, chrs, starts, ends)); });
+}
+// decoded bundle as the ctg.tsv text of `gams tsv` (one line per ctg, key order)
+char *gams_host_bincode_ctg_bundle_decode(const uint8_t *bytes, uint64_t n) {
+    return guarded([&] { return gams::tsv_ctgs(gams::wire::bincode_ctg_bundle_decode(bytes, n)); });
+}
+// intervals as parallel arrays; vals: n NUL-terminated strings (NULL = all empty, the idx:rg case)
+char *gams_host_bincode_lapper(uint64_t n, const uint32_t *starts, const uint32_t *stops, const char *const *vals,
+                               uint64_t *out_len) {
+    return guarded_bytes(out_len, [&] {
+        std::vector<gams::wire::LapperIv> ivs(n);
+        for (uint64_t i = 0; i < n; ++i) {
+            ivs[i].start = starts[i];
+            ivs[i].stop = stops[i];
+            if (vals && vals[i]) ivs[i].val = vals[i];
+        }
+        return gams::wire::bincode_lapper(ivs);
+    });
+}
+// decoded Lapper as text: "start\tstop\tval" per interval, then "#starts ...", "#stops ...", "#max_len N cov C merged B"
+char *gams_host_bincode_lapper_decode(const uint8_t *bytes, uint64_t n) {
+    return guarded([&] {
+        const gams::wire::LapperBlob b = gams::wire::bincode_lapper_decode(bytes, n);
+        std::string o;
+        for (const auto &v : b.intervals) o += std::to_string(v.start) + "\t" + std::to_string(v.stop) + "\t" + v.val + "\n";
+        o += "#starts";
+        for (uint32_t x : b.starts) o += " " + std::to_string(x);
+        o += "\n#stops";
+        for (uint32_t x : b.stops) o += " " + std::to_string(x);
+        o += "\n#max_len " + std::to_string(b.max_len) + " cov " + (b.has_cov ? std::to_string(b.cov) : std::string("None")) +
+             " merged " + (b.overlaps_merged ? "true" : "false") + "\n";
+        return o;
+    });
+}
+// args: n byte strings (arg_len[i] bytes each)
+char *gams_host_resp_command(uint32_t n, const char *const *args, const uint64_t *arg_len, uint64_t *out_len) {
+    return guarded_bytes(out_len, [&] {
+        std::vector<std::string> a(n);
+        for (uint32_t i = 0; i < n; ++i) a[i].assign(args[i], (size_t)arg_len[i]);
+        return gams::wire::resp_command(a);
+    });
+}
+char *gams_host_resp_scan_values(const char *pattern, uint64_t *out_len) {
+    return guarded_bytes(out_len, [&] {
+        return gams::wire::resp_eval(gams::wire::scan_values_script(), {}, {pattern ? pattern : "", "1000"});
+    });
+}
+// parses one reply; returns its flat text form (resp_dump), *consumed = bytes used (0: incomplete, "" returned)
+char *gams_host_resp_parse(const char *bytes, uint64_t n, uint64_t *consumed) {
+    return guarded([&] {
+        gams::wire::RespValue v;
+        const size_t used = gams::wire::resp_parse(bytes, n, v);
+        if (consumed) *consumed = used;
+        return used ? gams::wire::resp_dump(v) : std::string();
+    });
+}
+
+// idx: blobs (n of them, blob i = blob_len[i] bytes) -> device index, one group per blob; NULL on error
+void *gams_host_index_from_lappers(void *h, uint32_t n, const uint8_t *const *blobs, const uint64_t *blob_len) {
+    try {
+        g_err.clear();
+        g_code = 0;
+        std::vector<gams::wire::LapperBlob> dec;
+        for (uint32_t i = 0; i < n; ++i) dec.push_back(gams::wire::bincode_lapper_decode(blobs[i], (size_t)blob_len[i]));
+        return gams::wire::index_from_lappers(static_cast<gams_gpu_t *>(h), dec);
+    } catch (const gams::Error &e) {
+        g_err = e.what();
+        g_code = e.code;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        g_code = -1;
+    }
+    return nullptr;
+}
 }  // extern "C"

@@ -183,3 +183,24 @@ def test_count_and_cover_sharded_over_handles_equal_single(eng, n_handles):
     assert np.array_equal(got, exp)
     for x in engs[1:]:
         x.close()
+
+
+def test_index_from_idx_blobs(eng):
+    """idx:rg:{ctg} blobs (bincode of rust-lapper's Lapper, redis.rs:276-303) -> device index -> Lapper::count:
+    the path a host takes that keeps the reference's Redis namespace."""
+    from gams_amd import host
+
+    rng = np.random.default_rng(91)
+    groups = [(np.sort(rng.integers(1, 500000, n)).astype(np.uint32)) for n in (0, 1, 700, 5000)]
+    blobs = [host.bincode_lapper(g, g + 1) for g in groups]
+    ix = host.index_from_lappers(eng, blobs)
+    qg = rng.integers(0, len(groups), 4000).astype(np.uint32)
+    qs = rng.integers(1, 500000, 4000).astype(np.uint32)
+    qe = qs + rng.integers(0, 3000, 4000).astype(np.uint32)
+    cnt = np.full(4000, -1, np.int32)
+    eng.check(eng.lib.gams_gpu_count(eng.h, ix, qg.ctypes.data, qs.ctypes.data, qe.ctypes.data, 4000, cnt.ctypes.data))
+    eng.lib.gams_index_destroy(eng.h, ix)
+    for g, st in enumerate(groups):
+        sel = np.flatnonzero(qg == g)
+        exp = np.searchsorted(st, qe[sel], "left") - np.searchsorted(st + 1, qs[sel].astype(np.int64) + 1, "left")
+        assert np.array_equal(cnt[sel], exp), g
