@@ -82,6 +82,8 @@ void gams_gpu_destroy(gams_gpu_t *h) {
         }
         if (h->aux_ev[k]) (void)hipEventDestroy(h->aux_ev[k]);
     }
+    for (auto &e : h->rd_ev)
+        if (e) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->k0) (void)hipEventDestroy(h->k0);
@@ -225,6 +227,11 @@ int gams_seqset_upload(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, const uint8_
         if (rc != GAMS_OK) return rc;
     }
     if (!s->uploaded) GAMS_HIP(h, hipEventCreateWithFlags(&s->uploaded, hipEventDisableTiming));
+    // passes queued earlier on any stream of the handle may still be reading these bytes
+    {
+        int rc = gams_order_after_readers(h, h->copy);
+        if (rc != GAMS_OK) return rc;
+    }
     const uint64_t len = s->len[i];
     for (uint64_t o = 0; o < len; o += gams_gpu::kStageBytes) {
         const size_t n = (size_t)std::min<uint64_t>(gams_gpu::kStageBytes, len - o);
@@ -272,6 +279,11 @@ int gams_seqset_upload_all(gams_gpu_t *h, gams_seqset_t *s, const uint8_t *const
     // streams onto (GPU_MAX_HW_QUEUES, 4 by default).  It starts behind whatever `copy` already
     // holds for this seqset (the memset of gams_seqset_create, earlier uploads).
     hipStream_t second = h->readback;
+    // passes queued earlier on any stream of the handle may still be reading these bytes
+    {
+        int rc = gams_order_after_readers(h, h->copy);
+        if (rc != GAMS_OK) return rc;
+    }
     GAMS_HIP(h, hipEventRecord(s->uploaded, h->copy));
     GAMS_HIP(h, hipStreamWaitEvent(second, s->uploaded, 0));
     auto work = [&](unsigned t) {
@@ -394,6 +406,17 @@ int gams_stage_ring(gams_gpu_t *h) {
             GAMS_HIP(h, hipEventCreateWithFlags(&h->stage_free[k], hipEventDisableTiming));
             GAMS_HIP(h, hipEventRecord(h->stage_free[k], h->copy));
         }
+    }
+    return GAMS_OK;
+}
+
+int gams_order_after_readers(gams_gpu_t *h, hipStream_t st) {
+    for (int k = 0; k < gams_gpu::kMaxWays; ++k) {
+        hipStream_t src = k == 0 ? h->compute : h->aux[k - 1];
+        if (!src) continue;
+        if (!h->rd_ev[k]) GAMS_HIP(h, hipEventCreateWithFlags(&h->rd_ev[k], hipEventDisableTiming));
+        GAMS_HIP(h, hipEventRecord(h->rd_ev[k], src));
+        GAMS_HIP(h, hipStreamWaitEvent(st, h->rd_ev[k], 0));
     }
     return GAMS_OK;
 }

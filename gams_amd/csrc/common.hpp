@@ -22,6 +22,7 @@ struct gams_gpu {
     static constexpr int kMaxWays = 4;
     hipStream_t aux[kMaxWays - 1] = {};
     hipEvent_t aux_ev[kMaxWays - 1] = {};
+    hipEvent_t rd_ev[kMaxWays] = {};   // uploads queue behind every stream that may still read a seqset
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t k0 = nullptr, k1 = nullptr;  // around the kernel of the last query-style call
     bool k_valid = false;
@@ -88,6 +89,8 @@ struct gams_seqset {
 // make the compute stream wait for every upload queued so far (no host blocking)
 int gams_seqset_wait_uploads(gams_gpu_t *h, gams_seqset_t *s);
 int gams_stage_ring(gams_gpu_t *h);   // allocate the pinned staging slots on first use
+// make `st` (a copy stream) wait for everything queued so far on the compute and auxiliary streams
+int gams_order_after_readers(gams_gpu_t *h, hipStream_t st);
 int gams_seqset_gcindex(gams_gpu_t *h, gams_seqset_t *s);
 void gams_seqset_gcindex_free(gams_seqset_t *s);
 

@@ -934,16 +934,18 @@ int gams_wave_peaks(gams_gpu_t *h, gams_wave_plan_t *p, const gams_peak_t **peak
         const uint64_t total = h->pin_scratch[0];
         const uint64_t worst = h->pin_scratch[1];
         if (worst > p->tile_cap) {
-            // some tile signalled more windows than its slot holds: give every tile a slot of
-            // tw records (the maximum possible) and run again
-            // (every way gets new slots, so every pass still held is run again: same inputs, same results)
-            p->tile_cap_req = p->tw;
+            // some tile signalled more windows than its slot holds: the device has reported the
+            // fullest tile (runs are deterministic, so that is what the slots need -- at GRCh38 step 1 a
+            // slot of tw records per tile would be ~50 GB per way) and every pass still held is run
+            // again into the new slots: same inputs, same results.  The run counter only steps back by
+            // the passes repeated, so the way rotation and the history gams_wave_plan_select sees stay.
+            p->tile_cap_req = (uint32_t)std::min<uint64_t>(p->tw, (worst + 15u) & ~(uint64_t)15u);
             const uint32_t age = p->sel_age;
             const uint32_t again = (uint32_t)std::min<uint64_t>(p->depth, p->run_idx);
             int rc = wave_sync_ways(h, p);
             if (rc == GAMS_OK) rc = wave_upload_geometry(h, p);
             if (rc == GAMS_OK) {
-                p->run_idx = 0;
+                p->run_idx -= again;
                 for (uint32_t k = 0; k < again && rc == GAMS_OK; ++k) rc = gams_wave_run(h, p);
                 p->sel_age = age;
             }

@@ -504,3 +504,51 @@ def test_guard_band_margin_on_small_inputs(eng, s288c):
         plan.set_guard(0.5, False)
     plan.close()
     ss.close()
+
+
+def test_reupload_is_ordered_behind_queued_passes(eng, s288c):
+    """an upload into a live seqset queues behind the passes already queued on every stream of
+    the handle, so a held pass keeps the results of the bytes it was queued on: run (old), upload, run (new);
+    select(1) = old content, select(0) = new content."""
+    a = synth(400000, 51).tobytes()
+    b = synth(400000, 52).tobytes()
+    ss = engine.SeqSet(eng, [a, bytes(s288c["Mito"])])
+    plan = engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS)
+    plan.set_depth(2)
+    exp = {}
+    for name, seq in (("a", a), ("b", b)):
+        _, _, sig = ora.wave_windows(seq, 100, 10, 100, 3.0, 1.0)
+        exp[name] = np.flatnonzero(sig)
+    for rep in range(5):
+        ss.upload(0, a)
+        plan.run_n(7)          # old content, several passes deep on both streams
+        ss.upload(0, b)        # must not overtake them
+        plan.run()
+        plan.select(1)
+        pk = plan.peaks()
+        assert np.array_equal(pk[pk["ctg"] == 0]["window"], exp["a"]), rep
+        plan.select(0)
+        pk = plan.peaks()
+        assert np.array_equal(pk[pk["ctg"] == 0]["window"], exp["b"]), rep
+    plan.close()
+    ss.close()
+
+
+def test_overflowing_tile_regrows_to_the_fullest_tile(eng, s288c):
+    """threshold -1 signals every window from `lag` on: the first peaks() regrows the slots (to the fullest
+    tile, not beyond), the held history survives, later runs do not regrow again."""
+    seq = bytes(s288c["Mito"])
+    ss = engine.SeqSet(eng, [seq, synth(50000, 61).tobytes()])
+    plan = engine.WavePlan(eng, ss, 100, 10, 100, -1.0, 1.0, flags=_lib.WAVE_PEAKS)
+    plan.set_depth(2)
+    plan.run_n(5)
+    n = [plan.ctg_windows(0), plan.ctg_windows(1)]
+    for age in (0, 1):
+        plan.select(age)
+        pk = plan.peaks()
+        assert pk.size == sum(x - 100 for x in n), age
+        assert np.array_equal(pk[pk["ctg"] == 0]["window"], np.arange(100, n[0]))
+    plan.run_n(3)
+    assert plan.peaks().size == sum(x - 100 for x in n)
+    plan.close()
+    ss.close()
