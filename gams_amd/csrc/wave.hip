@@ -24,7 +24,7 @@
 // steps, very large lags) run untiled: wave_direct_count_kernel + wave_direct_signal_kernel.
 //
 // influence != 1 makes filtered[] (stat.rs:42) a true serial recurrence: those
-// runs use wave_serial_kernel (one lane per ctg, exact f32 order) on the counts of a
+// runs use wave_serial_wave_kernel (one wavefront per ctg, exact f32 order; one lane per ctg beyond lag 16383) on the counts of a
 // counts-only tile pass, then wave_compact_kernel.
 //
 // Compile with -ffp-contract=off: the exact paths must not fuse (x-m)*(x-m)+acc.
@@ -660,8 +660,17 @@ static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
     }
     if (p->serial) {
         const uint32_t n = p->set->n_ctg;
-        hipLaunchKernelGGL(wave_serial_kernel, dim3((n + 63) / 64), dim3(64), 0, st, p->d_ctgs, n, w.d_dense_cnt,
-                           w.d_dense_sig, w.d_filtered, q.lag, q.threshold, q.influence, (float)q.size);
+        if (q.lag + 1u <= kSerialRing) {
+            // one wavefront per ctg, the last lag + 1 filtered values in an LDS ring
+            const size_t ring = (size_t)((q.lag + 1u + 63u) & ~63u) * sizeof(float);
+            GAMS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(wave_serial_wave_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSerialRing * sizeof(float))));
+            hipLaunchKernelGGL(wave_serial_wave_kernel, dim3(n), dim3(64), ring, st, p->d_ctgs, n, w.d_dense_cnt,
+                               w.d_dense_sig, q.lag, q.threshold, q.influence, (float)q.size);
+        } else {
+            hipLaunchKernelGGL(wave_serial_kernel, dim3((n + 63) / 64), dim3(64), 0, st, p->d_ctgs, n, w.d_dense_cnt,
+                               w.d_dense_sig, w.d_filtered, q.lag, q.threshold, q.influence, (float)q.size);
+        }
         GAMS_HIP(h, hipGetLastError());
         if (p->flags & GAMS_WAVE_PEAKS) {
             hipLaunchKernelGGL(wave_compact_kernel, dim3((unsigned)p->tiles.size()), dim3(256), 0, st, p->d_ctgs,

@@ -981,6 +981,67 @@ __global__ void wave_serial_kernel(const WaveCtgDev *ctgs, uint32_t n_ctg, const
     }
 }
 
+// The same recurrence with one WAVEFRONT per ctg (lag + 1 <= kSerialRing): the last lag + 1 values of
+// filtered[] live in an LDS ring, the lanes fetch the lag values of a window in parallel and only the
+// two f32 sums stay sequential (seq_add_lanes: the reference's left-to-right order), so a window costs
+// ~2.4k cycles at lag 100 instead of 2 * lag dependent global loads on a single lane (a 500-kb ctg at
+// step 10 took minutes).  Every lane computes the same decision; lane 0 stores.
+constexpr uint32_t kSerialRing = 16384;   // floats of LDS ring (64 KiB)
+__global__ __launch_bounds__(64) void wave_serial_wave_kernel(const WaveCtgDev *ctgs, uint32_t n_ctg,
+                                                              const uint32_t *dense_cnt, int8_t *dense_sig,
+                                                              uint32_t lag, float thr, float influence,
+                                                              float fsize) {
+    extern __shared__ float ring[];       // ring[q % R] = filtered[q], R = lag + 1 rounded up to 64
+    const uint32_t c = blockIdx.x, lane = threadIdx.x;
+    if (c >= n_ctg) return;
+    const WaveCtgDev cg = ctgs[c];
+    const uint32_t n = cg.n_win;
+    const uint32_t *k = dense_cnt + cg.win_base;
+    int8_t *sig = dense_sig + cg.win_base;
+    const uint32_t R = (lag + 1u + 63u) & ~63u;
+    for (uint32_t i = lane; i < n; i += 64u) sig[i] = 0;
+    if (n < lag || lag == 0) return;
+    for (uint32_t q = lane; q < lag; q += 64u) ring[q] = (float)k[q] / fsize;   // filtered = data (stat.rs:21)
+    __builtin_amdgcn_s_waitcnt(0xc07f);                                          // lgkmcnt(0): one wave, no barrier needed
+    const float len = (float)lag;
+    // mean and sample sd of filtered[first, first + lag), in the reference's order (stat.rs:1-14)
+    auto stats = [&](uint32_t first, float &avg, float &sd) {
+        float sum = 0.0f;
+        for (uint32_t c0 = 0; c0 < lag; c0 += 64u) {
+            const float x = c0 + lane < lag ? ring[(first + c0 + lane) % R] : 0.0f;
+            sum = seq_add_lanes(sum, x, min(64u, lag - c0));
+        }
+        avg = sum / len;
+        float sq = 0.0f;
+        for (uint32_t c0 = 0; c0 < lag; c0 += 64u) {
+            const float x = ring[(first + min(c0 + lane, lag - 1u)) % R];
+            const float d = x - avg;
+            const float dd = c0 + lane < lag ? d * d : 0.0f;
+            sq = seq_add_lanes(sq, dd, min(64u, lag - c0));
+        }
+        sd = sqrtf(sq / (len - 1.0f));
+    };
+    float avg, sd;
+    stats(0u, avg, sd);                                                          // stat.rs:30-31
+    for (uint32_t i = lag; i < n; ++i) {
+        const float x = (float)k[i] / fsize;
+        float f = x;
+        int sg = 0;
+        if (fabsf(x - avg) > thr * sd) {                                         // stat.rs:36
+            sg = x > avg ? 1 : -1;
+            const float a = influence * x;
+            const float b = (1.0f - influence) * ring[(i - 1u) % R];
+            f = a + b;                                                           // stat.rs:42
+        }
+        if (lane == 0) {
+            if (sg) sig[i] = (int8_t)sg;
+            ring[i % R] = f;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        stats(i - lag, avg, sd);                                                 // stat.rs:51-52: [i - lag, i)
+    }
+}
+
 // Ordered compaction of dense signals (serial path): same tile/offset scheme as
 // phase 4 of wave_tile_kernel.
 __global__ __launch_bounds__(256) void wave_compact_kernel(const WaveCtgDev *ctgs, const WaveTile *tiles,

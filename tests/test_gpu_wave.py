@@ -552,3 +552,26 @@ def test_overflowing_tile_regrows_to_the_fullest_tile(eng, s288c):
     assert plan.peaks().size == sum(x - 100 for x in n)
     plan.close()
     ss.close()
+
+
+@pytest.mark.parametrize("lag,infl,thr", [(100, 0.5, 3.0), (64, 0.0, 2.0), (65, 0.25, 2.5), (7, 0.9, 1.5), (200, 1.5, 3.0),
+                                          (128, -0.5, 2.0)])
+def test_influence_recurrence_one_wave_per_ctg(eng, s288c, lag, infl, thr):
+    """influence != 1 (stat.rs:42): the filtered[] recurrence, one wavefront per ctg with an LDS ring; several ctgs
+    of different lengths in one batch, lags around the 64-lane chunk size, influences outside [0, 1]."""
+    seqs = [bytes(s288c["Mito"][:40000]), synth(25000, 71).tobytes(), synth(lag * 10 + 99, 72).tobytes(),
+            bytes(s288c["I"][:60000])]
+    ss = engine.SeqSet(eng, seqs)
+    plan = engine.WavePlan(eng, ss, 100, 10, lag, thr, infl, flags=_lib.WAVE_PEAKS | _lib.WAVE_DENSE)
+    plan.run()
+    pk = plan.peaks()
+    for c, s in enumerate(seqs):
+        ocnt, _, osig = ora.wave_windows(s, 100, 10, lag, thr, infl)
+        cnt, sig = plan.dense(c)
+        assert np.array_equal(cnt, ocnt)
+        bad = np.flatnonzero(sig.astype(np.int32) != osig)
+        assert bad.size == 0, (c, bad[:5])
+        idx = np.flatnonzero(osig)
+        assert np.array_equal(pk[pk["ctg"] == c]["window"], idx)
+    plan.close()
+    ss.close()
