@@ -407,7 +407,7 @@ int wave_launch_fast(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a, hipS
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
         p->attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)p->tiles.size()), dim3(256), p->lds_bytes, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)p->tiles.size()), dim3(256), p->lds_bytes, st, a.tiles, a.seq, a);
     GAMS_HIP(h, hipGetLastError());
     return GAMS_OK;
 }

@@ -454,11 +454,14 @@ __device__ __forceinline__ void z_decide(float nf, float kkf, float S1f, float S
 // SIZE/STEP/LAG != 0 bake the headline parameters into the instruction stream (constant
 // bit-field offsets in phase 2); 0 = taken from the arguments at run time.
 template <int W, int SIZE, int STEP, int LAG>
-__global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
+// `tiles` and `seq` are kernel parameters of their own, in front of the argument block: with
+// -mllvm -amdgpu-kernarg-preload-count the command processor delivers the first kernel-argument
+// dwords in SGPRs at wave start, so the tile descriptor's load does not wait for a scalar load of
+// the arguments first (two dependent round trips before a workgroup's first sequence load -> one).
+__global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveTile *const tiles_p, const uint8_t *const seq_p,
+                                                           const WaveArgs a) {
     static_assert(W % 4 == 0 && (((W / 4) & 1) == 1 || W == 8), "W/4 odd (LDS bank stride), or W = 8 (64-bit reads)");
     static_assert((SIZE == 0) == (STEP == 0) && (SIZE == 0) == (LAG == 0), "bake all three or none");
-    if (a.stamps != nullptr && threadIdx.x == 0)
-        a.stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();  // workgroup entry
     // Windows per tile.  Baked parameters: 256*W - LAG - 1, so that the tile's K slots (its windows
     // plus the lag+1 in front) are exactly 256*W: every thread of phase 2 owns W slots, which are
     // also the block of outgoing counts of the phase-3 thread with the same index.
@@ -476,7 +479,9 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
     uint8_t *SG = reinterpret_cast<uint8_t *>(PS + 272);
 
     const uint32_t tid = threadIdx.x;
-    const WaveTile tl = a.tiles[blockIdx.x];
+    const WaveTile tl = tiles_p[blockIdx.x];         // issued before anything waits for the argument block
+    if (a.stamps != nullptr && threadIdx.x == 0)
+        a.stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();  // workgroup entry
     const struct { uint64_t seq_off, win_base; uint32_t n_win; } cg = {tl.seq_off, tl.win_base, tl.n_win};
     const uint32_t lag = LAG ? (uint32_t)LAG : a.lag, step = STEP ? (uint32_t)STEP : a.step,
                    size = SIZE ? (uint32_t)SIZE : a.size;
@@ -489,7 +494,7 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveArgs a) {
     const uint32_t a0 = b0 & ~15u;
     const uint32_t b1 = (w1 - 1u) * step + size;
     const uint32_t nchunk = (b1 - a0 + 15u) >> 4;
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.seq + cg.seq_off + a0);
+    const uint4 *src = reinterpret_cast<const uint4 *>(seq_p + cg.seq_off + a0);
 
     wave_stamp(a, 0);
     // ---- phase 1: load + classify ------------------------------------------
