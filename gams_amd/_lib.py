@@ -45,6 +45,8 @@ PROTOTYPES = {
     "gams_gpu_timer_start": (C.c_int, [_VP]),
     "gams_gpu_timer_stop": (C.c_int, [_VP, C.POINTER(C.c_float)]),
     "gams_gpu_last_kernel_ms": (C.c_int, [_VP, C.POINTER(C.c_float)]),
+    "gams_gpu_host_alloc": (C.c_int, [_VP, C.c_uint64, _PP]),
+    "gams_gpu_host_free": (None, [_VP, _VP]),
     "gams_window_count": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     "gams_seqset_create": (C.c_int, [_VP, C.c_uint32, _VP, _PP]),
     "gams_seqset_upload": (C.c_int, [_VP, _VP, C.c_uint32, _VP]),

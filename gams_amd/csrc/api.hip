@@ -86,6 +86,13 @@ void gams_gpu_destroy(gams_gpu_t *h) {
         if (e) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (auto &slot : h->q_ev)
+        for (auto &e : slot)
+            if (e) (void)hipEventDestroy(e);
+    for (auto &pr : h->kq) {
+        if (pr.first) (void)hipEventDestroy(pr.first);
+        if (pr.second) (void)hipEventDestroy(pr.second);
+    }
     if (h->k0) (void)hipEventDestroy(h->k0);
     if (h->k1) (void)hipEventDestroy(h->k1);
     for (int k = 0; k < gams_gpu::kStageSlots; ++k) {
@@ -166,9 +173,36 @@ int gams_gpu_last_kernel_ms(gams_gpu_t *h, float *ms) {
     if (!h || !ms) return gams_fail(h, GAMS_EINVAL, "last_kernel_ms: null argument");
     if (!h->k_valid) return gams_fail(h, GAMS_ESTATE, "last_kernel_ms: no timed call yet");
     GAMS_HIP(h, hipSetDevice(h->device));
+    if (h->kq_used > 0) {          // a chunked query call: the sum of its kernels
+        float total = 0.0f;
+        for (int c = 0; c < h->kq_used; ++c) {
+            float part = 0.0f;
+            GAMS_HIP(h, hipEventSynchronize(h->kq[c].second));
+            GAMS_HIP(h, hipEventElapsedTime(&part, h->kq[c].first, h->kq[c].second));
+            total += part;
+        }
+        *ms = total;
+        return GAMS_OK;
+    }
     GAMS_HIP(h, hipEventSynchronize(h->k1));
     GAMS_HIP(h, hipEventElapsedTime(ms, h->k0, h->k1));
     return GAMS_OK;
+}
+
+int gams_gpu_host_alloc(gams_gpu_t *h, uint64_t bytes, void **p) {
+    if (!h || !p) return gams_fail(h, GAMS_EINVAL, "host_alloc: null argument");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    hipError_t e = hipHostMalloc(p, std::max<uint64_t>(bytes, 1), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return gams_fail(h, GAMS_ENOMEM, std::string("host_alloc: ") + hipGetErrorString(e));
+    }
+    return GAMS_OK;
+}
+
+void gams_gpu_host_free(gams_gpu_t *h, void *p) {
+    if (h) (void)hipSetDevice(h->device);
+    if (p) (void)hipHostFree(p);
 }
 
 // ---------------------------------------------------------------------------

@@ -26,6 +26,11 @@ struct gams_gpu {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t k0 = nullptr, k1 = nullptr;  // around the kernel of the last query-style call
     bool k_valid = false;
+    // chunked query calls (gams_gpu_count / locate / cover): per-slot ordering events and one timed pair
+    // per chunk; gams_gpu_last_kernel_ms sums the pairs of the last call when kq_used > 0
+    hipEvent_t q_ev[2][3] = {};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> kq;
+    int kq_used = 0;
     // pinned staging ring of the copy stream: the CPU fills slot k+1 while the DMA drains slot k
     static constexpr int kStageSlots = 4;
     static constexpr size_t kStageBytes = 16u << 20;

@@ -112,6 +112,7 @@ extern "C" int gams_gpu_valid_spans(gams_gpu_t *h, const uint8_t *seq, uint64_t 
         G_HIP(hipGetLastError());
         G_HIP(hipEventRecord(h->k1, h->compute));
         h->k_valid = true;
+    h->kq_used = 0;
         unsigned long long nf = 0;
         G_HIP(hipMemcpyAsync(&nf, d_n, sizeof nf, hipMemcpyDeviceToHost, h->compute));
         G_HIP(hipStreamSynchronize(h->compute));

@@ -51,7 +51,28 @@ struct IndexGroup {
     uint64_t off;     // first interval of the group
     uint32_t n;       // intervals in the group
     uint32_t maxlen;  // max(stop - start), Lapper::max_len
-    KeyDir start, stop;
+    KeyDir start, stop;       // one bucket per key, rank only (locate's lower bound)
+    KeyDir bk_start, bk_stop; // ~four keys per bucket, rank + the next seven keys inline (count's two lower bounds)
+};
+
+// What a count query needs of its group, one 32-B record (the 80-B IndexGroup costs a second line and
+// three more loads per query; random queries are bound by lines moved, not by bytes)
+struct CountGroup {
+    uint32_t off, n;                 // first interval (m < 2^32), intervals
+    uint32_t s_key0, s_nb;           // bucket records over the starts
+    uint32_t t_key0, t_nb;           // ... over the stops
+    uint32_t s_shift, t_shift;
+};
+
+// Bucket record of the count path: everything a lower bound needs in ONE 32-B access -- the rank of
+// the first key at or after the bucket's edge and the seven keys that follow it (0xffffffff past the
+// group's end).  A key that falls in bucket b is compared with those seven; only when all seven are
+// smaller (a bucket of more than seven keys: 5 % of uniform buckets) the search goes on in the key
+// array.  Random queries are bound by scattered lines out of the Infinity Cache: the separate
+// directory + key array of the locate path cost two lines per bound, this one.
+struct BkRec {
+    uint32_t rank;
+    uint32_t k[7];
 };
 
 struct SpanRec {
@@ -73,8 +94,10 @@ struct gams_index {
     uint32_t *d_stops = nullptr;     // per group, ascending, sorted independently (for count)
     uint32_t *d_lstart = nullptr;    // per group, starts of the (start,stop)-sorted pairs: ascending (both searches)
     IvRec *d_lrec = nullptr;         // the sorted pairs + the caller's index of each, 16 B (locate's scan)
-    uint32_t *d_dir_start = nullptr; // m + n_groups entries: group g's directory begins at off[g] + g
-    uint32_t *d_dir_stop = nullptr;
+    uint32_t *d_dir_start = nullptr; // m + n_groups entries: group g's directory begins at off[g] + g (locate)
+    BkRec *d_bk_start = nullptr;     // m/4 + 2*n_groups + 2 records: group g's begin at off[g]/4 + 2g
+    BkRec *d_bk_stop = nullptr;
+    CountGroup *d_cgroups = nullptr;
     // everything above lives in one pooled HBM block
     uint8_t *arena = nullptr;
     size_t arena_bytes = 0;
@@ -109,9 +132,34 @@ __device__ __forceinline__ uint32_t dir_lower_bound(const uint32_t *a, const uin
     return lo;
 }
 
-__global__ __launch_bounds__(256) void interval_count_kernel(const IndexGroup *groups, const uint32_t *starts,
-                                                             const uint32_t *stops, const uint32_t *dir_start,
-                                                             const uint32_t *dir_stop, uint32_t n_groups,
+// lower bound through the bucket records (see BkRec)
+__device__ __forceinline__ uint32_t bk_lower_bound(const uint32_t *keys, const BkRec *bk, uint32_t n, const KeyDir d,
+                                                   uint64_t key) {
+    if (n == 0 || key <= (uint64_t)d.key0) return 0;
+    const uint64_t b = (key - d.key0) >> d.shift;
+    if (b >= d.nb) return n;
+    const uint4 *rp = reinterpret_cast<const uint4 *>(bk + b);
+    const uint4 r0 = rp[0], r1 = rp[1];
+    const uint32_t rank = r0.x;
+    uint32_t c = (uint32_t)((uint64_t)r0.y < key) + (uint32_t)((uint64_t)r0.z < key) + (uint32_t)((uint64_t)r0.w < key) +
+                 (uint32_t)((uint64_t)r1.x < key) + (uint32_t)((uint64_t)r1.y < key) + (uint32_t)((uint64_t)r1.z < key) +
+                 (uint32_t)((uint64_t)r1.w < key);
+    c = min(c, n - rank);                            // padding past the group's end does not count
+    if (c < 7u || rank + 7u >= n) return rank + c;
+    uint32_t lo = rank + 7u, hi = n;                 // a crowded bucket: go on in the key array
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((uint64_t)keys[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void interval_count_kernel(const CountGroup *groups, const uint32_t *starts,
+                                                             const uint32_t *stops, const BkRec *bk_start,
+                                                             const BkRec *bk_stop, uint32_t n_groups,
                                                              const uint32_t *group, const uint32_t *qs,
                                                              const uint32_t *qe, uint64_t nq, int32_t *out) {
     const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -121,10 +169,14 @@ __global__ __launch_bounds__(256) void interval_count_kernel(const IndexGroup *g
         out[q] = 0;
         return;
     }
-    const IndexGroup G = groups[g];
+    const uint4 *gp = reinterpret_cast<const uint4 *>(groups + g);
+    const uint4 g0 = gp[0], g1 = gp[1];
+    const uint32_t off = g0.x, n = g0.y;
+    const KeyDir ds{g0.z, g1.z, g0.w, 0u}, dt{g1.x, g1.w, g1.y, 0u};
+    const uint64_t boff = (uint64_t)(off >> 2) + 2ull * g;
     // Lapper::count: first = bsearch_seq(start + 1, stops); last = bsearch_seq(stop, starts)
-    const uint32_t first = dir_lower_bound<0u>(stops + G.off, dir_stop + G.off + g, G.n, G.stop, (uint64_t)qs[q] + 1u);
-    const uint32_t last = dir_lower_bound<0u>(starts + G.off, dir_start + G.off + g, G.n, G.start, (uint64_t)qe[q]);
+    const uint32_t first = bk_lower_bound(stops + off, bk_stop + boff, n, dt, (uint64_t)qs[q] + 1u);
+    const uint32_t last = bk_lower_bound(starts + off, bk_start + boff, n, ds, (uint64_t)qe[q]);
     out[q] = (int32_t)((int64_t)last - (int64_t)first);
 }
 
@@ -246,7 +298,8 @@ __device__ __forceinline__ KeyDir dir_params(uint32_t first, uint32_t last, uint
 // one wavefront per group: max(stop - start) (Lapper::max_len) and the directory headers
 __global__ __launch_bounds__(64) void index_group_kernel(const uint32_t *off32, uint32_t n_groups,
                                                          const IvRec *lrec, const uint32_t *lstart,
-                                                         const uint32_t *stops_sorted, IndexGroup *groups) {
+                                                         const uint32_t *stops_sorted, IndexGroup *groups,
+                                                         CountGroup *cgroups) {
     const uint32_t g = blockIdx.x;
     if (g >= n_groups) return;
     const uint32_t lo = off32[g], hi = off32[g + 1], n = hi - lo;
@@ -263,7 +316,11 @@ __global__ __launch_bounds__(64) void index_group_kernel(const uint32_t *off32, 
         G.maxlen = ml;
         G.start = n ? dir_params(lstart[lo], lstart[hi - 1], n) : KeyDir{0u, 0u, 0u, 0u};
         G.stop = n ? dir_params(stops_sorted[lo], stops_sorted[hi - 1], n) : KeyDir{0u, 0u, 0u, 0u};
+        G.bk_start = n ? dir_params(lstart[lo], lstart[hi - 1], n / 4u + 1u) : KeyDir{0u, 0u, 0u, 0u};
+        G.bk_stop = n ? dir_params(stops_sorted[lo], stops_sorted[hi - 1], n / 4u + 1u) : KeyDir{0u, 0u, 0u, 0u};
         groups[g] = G;
+        cgroups[g] = CountGroup{lo, n, G.bk_start.key0, G.bk_start.nb, G.bk_stop.key0, G.bk_stop.nb, G.bk_start.shift,
+                                G.bk_stop.shift};
     }
 }
 
@@ -271,8 +328,7 @@ __global__ __launch_bounds__(64) void index_group_kernel(const uint32_t *off32, 
 // (its bucket b = j - off[g] - g); dir[b] = rank of the first key >= key0 + (b << shift), dir[nb] = n
 __global__ __launch_bounds__(256) void index_dir_kernel(const uint32_t *off32, uint32_t n_groups, uint64_t slots,
                                                         const IndexGroup *groups, const uint32_t *lstart,
-                                                        const uint32_t *stops_sorted, uint32_t *dir_start,
-                                                        uint32_t *dir_stop) {
+                                                        uint32_t *dir_start) {
     const uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (j >= slots) return;
     uint32_t lo = 0, hi = n_groups;                 // last group with off[g] + g <= j
@@ -304,7 +360,44 @@ __global__ __launch_bounds__(256) void index_dir_kernel(const uint32_t *off32, u
         dir[j] = G.n == 0 ? 0u : r;
     };
     fill(lstart, G.start, dir_start);
-    fill(stops_sorted, G.stop, dir_stop);
+}
+
+// bucket records of the count path: slot j belongs to the group g with off[g]/4 + 2g <= j, bucket b = j - that
+__global__ __launch_bounds__(256) void index_bk_kernel(const uint32_t *off32, uint32_t n_groups, uint64_t slots,
+                                                       const IndexGroup *groups, const uint32_t *lstart,
+                                                       const uint32_t *stops_sorted, BkRec *bk_start, BkRec *bk_stop) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (j >= slots) return;
+    uint32_t lo = 0, hi = n_groups;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((uint64_t)(off32[mid] >> 2) + 2ull * mid <= j)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint32_t g = lo;
+    const IndexGroup G = groups[g];
+    const uint64_t b = j - ((uint64_t)(off32[g] >> 2) + 2ull * g);
+    auto fill = [&](const uint32_t *keys, const KeyDir d, BkRec *bk) {
+        if (G.n == 0 || b >= d.nb) return;
+        const uint64_t edge = (uint64_t)d.key0 + (b << d.shift);
+        uint32_t a = 0, z = G.n;
+        while (a < z) {
+            const uint32_t mid = a + ((z - a) >> 1);
+            if ((uint64_t)keys[G.off + mid] < edge)
+                a = mid + 1;
+            else
+                z = mid;
+        }
+        BkRec r;
+        r.rank = a;
+#pragma unroll
+        for (uint32_t i = 0; i < 7u; ++i) r.k[i] = a + i < G.n ? keys[G.off + a + i] : 0xffffffffu;
+        bk[j] = r;
+    };
+    fill(lstart, G.bk_start, bk_start);
+    fill(stops_sorted, G.bk_stop, bk_stop);
 }
 
 // Host side of the directory: keys[0..n) ascending (already biased); dir gets nb+1 <= n+1 entries.
@@ -373,6 +466,92 @@ struct QueryBuf {
     }
 };
 
+#define Q_HIP(call)                                                                            \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return gams_fail(h, GAMS_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// Host columns in, one host column out, through the three query kernels.  The queries go in chunks of
+// 2^21: chunk c+1 is copied in (copy stream) while chunk c is searched (compute stream) and chunk c-1 is
+// copied out (readback stream), two device slots.  With page-locked host arrays (gams_gpu_host_alloc) the
+// three overlap and the call runs at the rate of the PCIe link; pageable arrays work, staged by the runtime.
+struct QCol {
+    const void *host;
+    size_t elem;
+};
+
+template <typename F>
+int query_pipeline(gams_gpu_t *h, uint64_t nq, const QCol *cols, int ncol, void *out_host, size_t out_elem, F launch) {
+    const uint64_t CH = std::min<uint64_t>(nq, 1ull << 21);
+    const uint64_t nchunk = (nq + CH - 1) / CH;
+    const int nslot = nchunk > 1 ? 2 : 1;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t slot_bytes = al(CH * out_elem);
+    for (int k = 0; k < ncol; ++k) slot_bytes += al(CH * cols[k].elem);
+    uint8_t *block = nullptr;
+    size_t block_cap = 0;
+    hipError_t e = gams_pool_alloc(h, false, slot_bytes * nslot, reinterpret_cast<void **>(&block), &block_cap);
+    if (e != hipSuccess)
+        return gams_fail(h, e == hipErrorOutOfMemory ? GAMS_ENOMEM : GAMS_EHIP,
+                         std::string("query buffers: ") + hipGetErrorString(e));
+    struct Guard {
+        gams_gpu_t *h;
+        uint8_t *p;
+        size_t cap;
+        ~Guard() {
+            (void)hipStreamSynchronize(h->copy);
+            (void)hipStreamSynchronize(h->compute);
+            (void)hipStreamSynchronize(h->readback);
+            gams_pool_free(h, false, p, cap);
+        }
+    } guard{h, block, block_cap};
+    for (int s = 0; s < 2; ++s)
+        for (int k = 0; k < 3; ++k)
+            if (!h->q_ev[s][k]) Q_HIP(hipEventCreateWithFlags(&h->q_ev[s][k], hipEventDisableTiming));
+    while (h->kq.size() < nchunk) {
+        hipEvent_t a = nullptr, b = nullptr;
+        Q_HIP(hipEventCreate(&a));
+        Q_HIP(hipEventCreate(&b));
+        h->kq.emplace_back(a, b);
+    }
+    h->kq_used = 0;
+    // whatever the caller queued on the compute stream before (index build, uploads) comes first
+    Q_HIP(hipEventRecord(h->k0, h->compute));
+    Q_HIP(hipStreamWaitEvent(h->copy, h->k0, 0));
+    std::vector<void *> d_in((size_t)ncol);
+    for (uint64_t c = 0; c < nchunk; ++c) {
+        const int s = (int)(c & 1);
+        const uint64_t lo = c * CH, n = std::min<uint64_t>(CH, nq - lo);
+        uint8_t *p = block + (size_t)s * slot_bytes;
+        if (c >= 2) Q_HIP(hipStreamWaitEvent(h->copy, h->q_ev[s][1], 0));       // chunk c-2's kernel has read its inputs
+        for (int k = 0; k < ncol; ++k) {
+            d_in[(size_t)k] = p;
+            Q_HIP(hipMemcpyAsync(p, static_cast<const uint8_t *>(cols[k].host) + lo * cols[k].elem, n * cols[k].elem,
+                                 hipMemcpyHostToDevice, h->copy));
+            p += al(CH * cols[k].elem);
+        }
+        void *d_out = p;
+        Q_HIP(hipEventRecord(h->q_ev[s][0], h->copy));
+        Q_HIP(hipStreamWaitEvent(h->compute, h->q_ev[s][0], 0));
+        if (c >= 2) Q_HIP(hipStreamWaitEvent(h->compute, h->q_ev[s][2], 0));    // chunk c-2's results are out
+        Q_HIP(hipEventRecord(h->kq[(size_t)c].first, h->compute));
+        launch(d_in.data(), d_out, n, h->compute);
+        Q_HIP(hipGetLastError());
+        Q_HIP(hipEventRecord(h->kq[(size_t)c].second, h->compute));
+        Q_HIP(hipEventRecord(h->q_ev[s][1], h->compute));
+        Q_HIP(hipStreamWaitEvent(h->readback, h->q_ev[s][1], 0));
+        Q_HIP(hipMemcpyAsync(static_cast<uint8_t *>(out_host) + lo * out_elem, d_out, n * out_elem,
+                             hipMemcpyDeviceToHost, h->readback));
+        Q_HIP(hipEventRecord(h->q_ev[s][2], h->readback));
+    }
+    h->kq_used = (int)nchunk;
+    h->k_valid = true;
+    Q_HIP(hipStreamSynchronize(h->readback));
+    return GAMS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -392,12 +571,15 @@ int gams_index_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
     // bucket directories and Lapper::max_len come from three small kernels over the sorted arrays.
     const uint32_t ng1 = std::max<uint32_t>(n_groups, 1);
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_cg = al((size_t)ng1 * sizeof(CountGroup));
     const size_t b_groups = al((size_t)ng1 * sizeof(IndexGroup)), b_u32 = al(std::max<uint64_t>(m, 1) * 4),
                  b_rec = al(std::max<uint64_t>(m, 1) * sizeof(IvRec)), b_dir = al((m + n_groups + 1) * 4);
+    const uint64_t bk_slots = m / 4 + 2ull * n_groups + 2;
+    const size_t b_bk = al(bk_slots * sizeof(BkRec));
     gams_index_t *ix = new gams_index_t();
     ix->n_groups = n_groups;
     ix->m = m;
-    hipError_t e = gams_pool_alloc(h, false, b_groups + 2 * b_u32 + b_rec + 2 * b_dir,
+    hipError_t e = gams_pool_alloc(h, false, b_groups + b_cg + 2 * b_u32 + b_rec + b_dir + 2 * b_bk,
                                    reinterpret_cast<void **>(&ix->arena), &ix->arena_bytes);
     // scratch: raw columns, packed keys in/out, permutation in/out, 32-bit offsets, radix-sort storage
     const size_t b_key = al(std::max<uint64_t>(m, 1) * 8), b_off = al(((size_t)n_groups + 1) * 4);
@@ -419,6 +601,8 @@ int gams_index_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
         uint8_t *p = ix->arena;
         ix->d_groups = reinterpret_cast<IndexGroup *>(p);
         p += b_groups;
+        ix->d_cgroups = reinterpret_cast<CountGroup *>(p);
+        p += b_cg;
         ix->d_stops = reinterpret_cast<uint32_t *>(p);
         p += b_u32;
         ix->d_lstart = reinterpret_cast<uint32_t *>(p);
@@ -427,7 +611,9 @@ int gams_index_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
         p += b_rec;
         ix->d_dir_start = reinterpret_cast<uint32_t *>(p);
         p += b_dir;
-        ix->d_dir_stop = reinterpret_cast<uint32_t *>(p);
+        ix->d_bk_start = reinterpret_cast<BkRec *>(p);
+        p += b_bk;
+        ix->d_bk_stop = reinterpret_cast<BkRec *>(p);
     }
     e = gams_pool_alloc(h, false, 2 * b_u32 + 2 * b_key + 2 * b_u32 + b_off, reinterpret_cast<void **>(&scratch),
                         &scratch_bytes);
@@ -474,13 +660,15 @@ int gams_index_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
     }
     if (n_groups) {
         hipLaunchKernelGGL(index_group_kernel, dim3(n_groups), dim3(64), 0, st, d_off32, n_groups, ix->d_lrec,
-                           ix->d_lstart, ix->d_stops, ix->d_groups);
+                           ix->d_lstart, ix->d_stops, ix->d_groups, ix->d_cgroups);
         if ((e = hipGetLastError()) != hipSuccess) return fail(e, "group records");
         const uint64_t slots = m + n_groups;        // the last group's directory ends at m + n_groups (inclusive slot)
         hipLaunchKernelGGL(index_dir_kernel, dim3((unsigned)((slots + 1 + 255) / 256)), dim3(256), 0, st, d_off32,
-                           n_groups, slots + 1, ix->d_groups, ix->d_lstart, ix->d_stops, ix->d_dir_start,
-                           ix->d_dir_stop);
+                           n_groups, slots + 1, ix->d_groups, ix->d_lstart, ix->d_dir_start);
         if ((e = hipGetLastError()) != hipSuccess) return fail(e, "directories");
+        hipLaunchKernelGGL(index_bk_kernel, dim3((unsigned)((bk_slots + 255) / 256)), dim3(256), 0, st, d_off32,
+                           n_groups, bk_slots, ix->d_groups, ix->d_lstart, ix->d_stops, ix->d_bk_start, ix->d_bk_stop);
+        if ((e = hipGetLastError()) != hipSuccess) return fail(e, "bucket records");
     }
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "index build");
     gams_pool_free(h, false, scratch, scratch_bytes);
@@ -499,12 +687,6 @@ void gams_index_destroy(gams_gpu_t *h, gams_index_t *ix) {
     delete ix;
 }
 
-#define Q_HIP(call)                                                                            \
-    do {                                                                                       \
-        hipError_t e_ = (call);                                                                \
-        if (e_ != hipSuccess)                                                                  \
-            return gams_fail(h, GAMS_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
-    } while (0)
 
 int gams_gpu_count(gams_gpu_t *h, gams_index_t *ix, const uint32_t *group, const uint32_t *qs,
                    const uint32_t *qe, uint64_t nq, int32_t *count) {
@@ -513,23 +695,13 @@ int gams_gpu_count(gams_gpu_t *h, gams_index_t *ix, const uint32_t *group, const
     if (nq == 0) return GAMS_OK;
     if ((nq + 255) / 256 > 0x7fffffffull) return gams_fail(h, GAMS_EUNSUPPORTED, "gpu_count: too many queries");
     GAMS_HIP(h, hipSetDevice(h->device));
-    QueryBuf qb(h);
-    uint32_t *d_g, *d_s, *d_e;
-    int32_t *d_o;
-    Q_HIP(qb.in(&d_g, group, nq, h->compute));
-    Q_HIP(qb.in(&d_s, qs, nq, h->compute));
-    Q_HIP(qb.in(&d_e, qe, nq, h->compute));
-    Q_HIP(qb.in(&d_o, (const int32_t *)nullptr, nq, h->compute));
-    Q_HIP(hipEventRecord(h->k0, h->compute));
-    hipLaunchKernelGGL(interval_count_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->compute,
-                       ix->d_groups, ix->d_lstart, ix->d_stops, ix->d_dir_start, ix->d_dir_stop, ix->n_groups, d_g,
-                       d_s, d_e, nq, d_o);
-    Q_HIP(hipGetLastError());
-    Q_HIP(hipEventRecord(h->k1, h->compute));
-    h->k_valid = true;
-    Q_HIP(hipMemcpyAsync(count, d_o, nq * sizeof(int32_t), hipMemcpyDeviceToHost, h->compute));
-    Q_HIP(hipStreamSynchronize(h->compute));
-    return GAMS_OK;
+    const QCol cols[3] = {{group, 4}, {qs, 4}, {qe, 4}};
+    return query_pipeline(h, nq, cols, 3, count, sizeof(int32_t), [&](void *const *d, void *d_out, uint64_t n, hipStream_t st) {
+        hipLaunchKernelGGL(interval_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ix->d_cgroups,
+                           ix->d_lstart, ix->d_stops, ix->d_bk_start, ix->d_bk_stop, ix->n_groups,
+                           static_cast<const uint32_t *>(d[0]), static_cast<const uint32_t *>(d[1]),
+                           static_cast<const uint32_t *>(d[2]), n, static_cast<int32_t *>(d_out));
+    });
 }
 
 int gams_gpu_locate(gams_gpu_t *h, gams_index_t *ix, const uint32_t *group, const uint32_t *qs,
@@ -539,23 +711,13 @@ int gams_gpu_locate(gams_gpu_t *h, gams_index_t *ix, const uint32_t *group, cons
     if (nq == 0) return GAMS_OK;
     if ((nq + 255) / 256 > 0x7fffffffull) return gams_fail(h, GAMS_EUNSUPPORTED, "gpu_locate: too many queries");
     GAMS_HIP(h, hipSetDevice(h->device));
-    QueryBuf qb(h);
-    uint32_t *d_g, *d_s, *d_e;
-    int64_t *d_o;
-    Q_HIP(qb.in(&d_g, group, nq, h->compute));
-    Q_HIP(qb.in(&d_s, qs, nq, h->compute));
-    Q_HIP(qb.in(&d_e, qe, nq, h->compute));
-    Q_HIP(qb.in(&d_o, (const int64_t *)nullptr, nq, h->compute));
-    Q_HIP(hipEventRecord(h->k0, h->compute));
-    hipLaunchKernelGGL(interval_locate_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->compute,
-                       ix->d_groups, ix->d_lstart, ix->d_lrec, ix->d_dir_start, ix->n_groups, d_g, d_s, d_e, nq,
-                       d_o);
-    Q_HIP(hipGetLastError());
-    Q_HIP(hipEventRecord(h->k1, h->compute));
-    h->k_valid = true;
-    Q_HIP(hipMemcpyAsync(hit, d_o, nq * sizeof(int64_t), hipMemcpyDeviceToHost, h->compute));
-    Q_HIP(hipStreamSynchronize(h->compute));
-    return GAMS_OK;
+    const QCol cols[3] = {{group, 4}, {qs, 4}, {qe, 4}};
+    return query_pipeline(h, nq, cols, 3, hit, sizeof(int64_t), [&](void *const *d, void *d_out, uint64_t n, hipStream_t st) {
+        hipLaunchKernelGGL(interval_locate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ix->d_groups,
+                           ix->d_lstart, ix->d_lrec, ix->d_dir_start, ix->n_groups, static_cast<const uint32_t *>(d[0]),
+                           static_cast<const uint32_t *>(d[1]), static_cast<const uint32_t *>(d[2]), n,
+                           static_cast<int64_t *>(d_out));
+    });
 }
 
 int gams_spans_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_off, const int32_t *lo,
@@ -623,25 +785,14 @@ int gams_gpu_cover(gams_gpu_t *h, gams_spans_t *sp, const uint32_t *group, const
     if (nq == 0) return GAMS_OK;
     if ((nq + 255) / 256 > 0x7fffffffull) return gams_fail(h, GAMS_EUNSUPPORTED, "gpu_cover: too many queries");
     GAMS_HIP(h, hipSetDevice(h->device));
-    QueryBuf qb(h);
-    uint32_t *d_g;
-    int32_t *d_cl, *d_ch, *d_s, *d_e;
-    float *d_o;
-    Q_HIP(qb.in(&d_g, group, nq, h->compute));
-    Q_HIP(qb.in(&d_cl, clip_lo, nq, h->compute));
-    Q_HIP(qb.in(&d_ch, clip_hi, nq, h->compute));
-    Q_HIP(qb.in(&d_s, qs, nq, h->compute));
-    Q_HIP(qb.in(&d_e, qe, nq, h->compute));
-    Q_HIP(qb.in(&d_o, (const float *)nullptr, nq, h->compute));
-    Q_HIP(hipEventRecord(h->k0, h->compute));
-    hipLaunchKernelGGL(span_cover_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, h->compute,
-                       sp->d_groups, sp->d_rec, sp->d_dir_lo, sp->n_groups, d_g, d_cl, d_ch, d_s, d_e, nq, d_o);
-    Q_HIP(hipGetLastError());
-    Q_HIP(hipEventRecord(h->k1, h->compute));
-    h->k_valid = true;
-    Q_HIP(hipMemcpyAsync(prop, d_o, nq * sizeof(float), hipMemcpyDeviceToHost, h->compute));
-    Q_HIP(hipStreamSynchronize(h->compute));
-    return GAMS_OK;
+    const QCol cols[5] = {{group, 4}, {clip_lo, 4}, {clip_hi, 4}, {qs, 4}, {qe, 4}};
+    return query_pipeline(h, nq, cols, 5, prop, sizeof(float), [&](void *const *d, void *d_out, uint64_t n, hipStream_t st) {
+        hipLaunchKernelGGL(span_cover_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sp->d_groups, sp->d_rec,
+                           sp->d_dir_lo, sp->n_groups, static_cast<const uint32_t *>(d[0]),
+                           static_cast<const int32_t *>(d[1]), static_cast<const int32_t *>(d[2]),
+                           static_cast<const int32_t *>(d[3]), static_cast<const int32_t *>(d[4]), n,
+                           static_cast<float *>(d_out));
+    });
 }
 
 }  // extern "C"

@@ -418,6 +418,7 @@ extern "C" int gams_gpu_sw(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, int32_t 
     SW_HIP(hipGetLastError());
     SW_HIP(hipEventRecord(h->k1, h->compute));
     h->k_valid = true;
+    h->kq_used = 0;
     SW_HIP(hipMemcpyAsync(rows, d_rows, n_out * sizeof(gams_sw_row_t), hipMemcpyDeviceToHost, h->compute));
     SW_HIP(hipStreamSynchronize(h->compute));
 #undef SW_HIP
@@ -476,6 +477,7 @@ extern "C" int gams_gpu_range_gc(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, in
     R_HIP(hipGetLastError());
     R_HIP(hipEventRecord(h->k1, h->compute));
     h->k_valid = true;
+    h->kq_used = 0;
     R_HIP(hipMemcpyAsync(gc, d_gc, n * sizeof(float), hipMemcpyDeviceToHost, h->compute));
     R_HIP(hipStreamSynchronize(h->compute));
 #undef R_HIP

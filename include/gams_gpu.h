@@ -67,6 +67,11 @@ int gams_gpu_timer_stop(gams_gpu_t *h, float *ms);
 /* Device time (HIP events around the kernel, excluding the host<->device copies) of the last
  * gams_gpu_sw / gams_gpu_count / gams_gpu_locate / gams_gpu_cover call on this handle. */
 int gams_gpu_last_kernel_ms(gams_gpu_t *h, float *ms);
+/* Page-locked host memory for query / result columns: gams_gpu_count, gams_gpu_locate and gams_gpu_cover
+ * move their columns in chunks (copy in, search, copy out on three streams); from page-locked arrays the
+ * three overlap and a call runs at the rate of the PCIe link.  Any host memory works. */
+int gams_gpu_host_alloc(gams_gpu_t *h, uint64_t bytes, void **p);
+void gams_gpu_host_free(gams_gpu_t *h, void *p);
 
 /* window.rs:78-94: number of size/step windows over `len` bases (-1: bad size/step) */
 int64_t gams_window_count(int64_t len, int32_t size, int32_t step);
