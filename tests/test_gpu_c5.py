@@ -22,15 +22,18 @@ def eng():
     e.close()
 
 
+SHARE = int(__import__("os").environ.get("GAMS_C5_SHARE", "8"))      # 1 = the whole of configs[4] (1e8 rg, 1e8 queries)
+
+
 @pytest.fixture(scope="module")
 def c5():
-    return synth.c5_workload(share=8)
+    return synth.c5_workload(share=SHARE)
 
 
 def test_c5_locate_count(eng, c5):
     w = c5
     nq = w["q_start"].size
-    assert w["n_ctg"] == 4000 and nq == 12_500_000 and w["rg_start"].size == 12_500_000
+    assert w["n_ctg"] == 32000 // SHARE and nq == 100_000_000 // SHARE and w["rg_start"].size == nq
     ix = C.c_void_p()
     eng.check(eng.lib.gams_index_create(eng.h, w["n_ctg"], w["rg_off"].ctypes.data, w["rg_start"].ctypes.data,
                                         w["rg_stop"].ctypes.data, C.byref(ix)))
@@ -125,3 +128,44 @@ def test_c5_anno(eng, c5):
         a, b = int(w["sp_off"][k]), int(w["sp_off"][k + 1])
         got = ora.anno_prop(w["sp_lo"][a:b], w["sp_hi"][a:b], int(cl[q]), int(ch[q]), int(s[q]), int(e[q]))
         assert np.float32(got) == prop[q]
+
+
+def test_c5_count_and_anno_over_eight_handles(eng, c5):
+    """configs[4] names 8 GPUs: `gams::count_multi` / `cover_multi` split the groups (ctgs / chromosomes) over 8
+    handles by LPT on their interval counts and route every query to the handle that owns its group (the path's only
+    exchange step); handle k sits on device k % device_count.  Same answers as one handle."""
+    import torch
+    from gams_amd import host
+
+    w = c5
+    nq = min(w["q_start"].size, 4_000_000)                       # the routing is what is new here
+    n_dev = max(1, torch.cuda.device_count())
+    engines = [engine.Engine(k % n_dev) for k in range(8)]
+    try:
+        got = host.count_multi(engines, w["rg_off"], w["rg_start"], w["rg_stop"], w["q_ctg"][:nq], w["q_start"][:nq],
+                               w["q_end"][:nq])
+        ix = C.c_void_p()
+        eng.check(eng.lib.gams_index_create(eng.h, w["n_ctg"], w["rg_off"].ctypes.data, w["rg_start"].ctypes.data,
+                                            w["rg_stop"].ctypes.data, C.byref(ix)))
+        one = np.zeros(nq, np.int32)
+        eng.check(eng.lib.gams_gpu_count(eng.h, ix, w["q_ctg"].ctypes.data, w["q_start"].ctypes.data,
+                                         w["q_end"].ctypes.data, nq, one.ctypes.data))
+        eng.lib.gams_index_destroy(eng.h, ix)
+        assert np.array_equal(got, one)
+        s = w["q_start"][:nq].astype(np.int32)
+        e = w["q_end"][:nq].astype(np.int32)
+        cl = (((s.astype(np.int64) - 1) // w["piece"]) * w["piece"] + 1).astype(np.int32)
+        ch = (cl + (w["piece"] - 1)).astype(np.int32)
+        cov = host.cover_multi(engines[:max(2, min(8, w["n_chr"]))], w["sp_off"], w["sp_lo"], w["sp_hi"], w["q_chr"][:nq],
+                               cl, ch, s, e)
+        sp = C.c_void_p()
+        eng.check(eng.lib.gams_spans_create(eng.h, w["n_chr"], w["sp_off"].ctypes.data, w["sp_lo"].ctypes.data,
+                                            w["sp_hi"].ctypes.data, C.byref(sp)))
+        ref = np.zeros(nq, np.float32)
+        eng.check(eng.lib.gams_gpu_cover(eng.h, sp, w["q_chr"].ctypes.data, cl.ctypes.data, ch.ctypes.data,
+                                         s.ctypes.data, e.ctypes.data, nq, ref.ctypes.data))
+        eng.lib.gams_spans_destroy(eng.h, sp)
+        assert np.array_equal(cov, ref)
+    finally:
+        for x in engines:
+            x.close()

@@ -186,3 +186,55 @@ def test_config2_sw_on_the_atha_genome(eng):
             assert x != x or (0.0 <= x <= 1.0) or (k == 3 and x >= 0.0)   # cv = stddev / mean may exceed 1
             assert len(v.split(".")[-1]) <= 4 or "e" in v               # round(.., 4), Rust {} formatting
     assert seen_feat == n_feat
+
+
+def test_config3_grch38_step1_sharded_over_eight_handles(eng):
+    """BASELINE configs[3] at full size: the GRCh38-shaped genome (24 chromosomes, 3.09 Gb, piece 1000000 ->
+    2,937 ctgs), size 100 / step 1 -> 3.09e9 windows.  The ctgs are LPT-sharded by window count over 8
+    handles the way `bench.py --workload GRCh38-step1 --gpus 8` shards them over 8 GPUs (device
+    k % device_count: one GPU on the test box); every shard runs on its own handle, and the shards' peaks
+    must equal (a) the oracle on every 30th ctg, record by record, and (b) the same ctgs' peaks when the
+    whole genome is one batch on one handle (sharding invariance).  GAMS_C3_SCALE shrinks the chromosomes."""
+    import os
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from gams_amd import shard
+
+    scale = float(os.environ.get("GAMS_C3_SCALE", "1.0"))
+    lengths = [int(x * scale) for x in synth.GRCH38_LENGTHS]
+    ctgs = synth.genome_ctgs(lengths, 1000000)
+    if scale == 1.0:
+        assert len(ctgs) == 2937
+    weights = [len(c["seq"]) - 100 + 1 for c in ctgs]
+    owner = shard.lpt_assign(weights, 8)
+    loads = [sum(w for w, o in zip(weights, owner) if o == r) for r in range(8)]
+    assert max(loads) <= 1.02 * sum(loads) / 8
+    # (b) one batch, one handle
+    ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])
+    whole, n = gpu_peaks(eng, ss, 100, 1, 100, 3.0)
+    ss.close()
+    assert n == sum(weights)
+    assert 0.01 < whole.size / n < 0.05
+    # eight shards, eight handles; a shard's ctgs keep their genome order, so its records are the
+    # subsequence of the whole run that belongs to its ctgs
+    n_dev = max(1, torch.cuda.device_count())
+    for r in range(8):
+        mine = np.asarray([i for i, o in enumerate(owner) if o == r], np.uint32)
+        e = engine.Engine(r % n_dev)
+        s = engine.SeqSet(e, [ctgs[i]["seq"] for i in mine])
+        pk, _ = gpu_peaks(e, s, 100, 1, 100, 3.0)
+        s.close()
+        e.close()
+        pk = pk.copy()
+        pk["ctg"] = mine[pk["ctg"]]
+        assert np.array_equal(pk, whole[np.isin(whole["ctg"], mine)]), r
+        del pk
+    # (a) the oracle on every 30th ctg, in parallel on the host
+    sample = list(range(0, len(ctgs), 30))
+    with ThreadPoolExecutor(16) as ex:
+        exp = list(ex.map(lambda i: oracle_peaks([ctgs[i]], 100, 1, 100, 3.0), sample))
+    first = np.searchsorted(whole["ctg"], np.arange(len(ctgs) + 1))
+    for i, rec in zip(sample, exp):
+        got = whole[first[i]:first[i + 1]].copy()
+        got["ctg"] = 0
+        assert np.array_equal(got, rec), i
