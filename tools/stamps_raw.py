@@ -77,3 +77,18 @@ ids = np.flatnonzero(full[:, 10] != 0)
 x = (full[ids, 11] >> np.uint64(32)).astype(int)
 print("blockIdx % 8 == XCC_ID for", int((ids % 8 == x).sum()), "of", ids.size, "workgroups;",
       "distinct (blockIdx % 8 -> xcc) pairs:", sorted(set(zip((ids % 8).tolist(), x.tolist())))[:16])
+# which blockIdx values share a CU (first round): dispatch order within a CU
+full_ids = ids
+cu_key = key  # xcc*1000 + se*100 + sh*16 + cu of the workgroups in `st` (same order as ids)
+first_round = full_ids < 2048
+by_cu = {}
+for b, k in zip(full_ids[first_round].tolist(), cu_key[first_round].tolist()):
+    by_cu.setdefault(k, []).append(b)
+shown = 0
+for k in sorted(by_cu)[:6]:
+    print("CU", k, "first-round blockIdx:", sorted(by_cu[k]))
+ks = np.array([len(v) for v in by_cu.values()])
+print("first-round workgroups per CU: min/median/max", ks.min(), np.median(ks), ks.max())
+# is slot k = blockIdx // 256 ?  (every CU would hold exactly one workgroup of every 256-block)
+ok = sum(1 for v in by_cu.values() if sorted(x // 256 for x in v) == list(range(len(v))))
+print("CUs whose first-round workgroups are one per 256-block of blockIdx:", ok, "of", len(by_cu))
