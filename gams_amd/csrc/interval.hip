@@ -446,26 +446,6 @@ hipError_t to_device(T **d, const T *hsrc, size_t n) {
     return e;
 }
 
-// scratch device copies of the query columns + result column: pooled HBM blocks of the handle
-// (a hipMalloc / hipFree pair per column and call cost more than the kernel)
-struct QueryBuf {
-    gams_gpu_t *h;
-    std::vector<std::pair<void *, size_t>> blocks;
-    explicit QueryBuf(gams_gpu_t *handle) : h(handle) {}
-    ~QueryBuf() {
-        for (auto &b : blocks) gams_pool_free(h, false, b.first, b.second);
-    }
-    template <typename T>
-    hipError_t in(T **d, const T *hsrc, uint64_t n, hipStream_t st) {
-        size_t cap = 0;
-        hipError_t e = gams_pool_alloc(h, false, std::max<uint64_t>(n, 1) * sizeof(T), reinterpret_cast<void **>(d), &cap);
-        if (e != hipSuccess) return e;
-        blocks.emplace_back(*d, cap);
-        if (n && hsrc) e = hipMemcpyAsync(*d, hsrc, n * sizeof(T), hipMemcpyHostToDevice, st);
-        return e;
-    }
-};
-
 #define Q_HIP(call)                                                                            \
     do {                                                                                       \
         hipError_t e_ = (call);                                                                \

@@ -54,7 +54,7 @@ stops = starts + 1
 ix = C.c_void_p()
 t0 = time.time()
 eng.check(lib.gams_index_create(eng.h, n_ctg, off.ctypes.data, starts.ctypes.data, stops.ctypes.data, C.byref(ix)))
-print(f"index_create ({m} intervals, {n_ctg} groups): {time.time() - t0:.2f} s host sort + upload")
+print(f"index_create ({m} intervals, {n_ctg} groups): {time.time() - t0:.2f} s upload + device sort + directories")
 nq = 12_500_000
 qg = rng.integers(0, n_ctg, nq).astype(np.uint32)
 qs = rng.integers(1, per, nq).astype(np.uint32)
