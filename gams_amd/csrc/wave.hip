@@ -399,9 +399,9 @@ int wave_launch(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a, hipStream
     return GAMS_OK;
 }
 
-template <int W, int SIZE, int STEP, int LAG>
-int wave_launch_fast(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a, hipStream_t st) {
-    auto kern = wave_fast_kernel<W, SIZE, STEP, LAG>;
+template <int W, int SIZE, int STEP, int LAG, bool NT>
+int wave_launch_fast_nt(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a, hipStream_t st) {
+    auto kern = wave_fast_kernel<W, SIZE, STEP, LAG, NT>;
     if (!p->attr_set) {
         GAMS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
@@ -410,6 +410,15 @@ int wave_launch_fast(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a, hipS
     hipLaunchKernelGGL(kern, dim3((unsigned)p->tiles.size()), dim3(256), p->lds_bytes, st, a.tiles, a.seq, a);
     GAMS_HIP(h, hipGetLastError());
     return GAMS_OK;
+}
+
+// sequence loads with the streaming hint once the batch is too large to live in L2 between passes
+// (kStreamBytes: twice the 32 MiB of L2)
+constexpr uint64_t kStreamBytes = 64ull << 20;
+template <int W, int SIZE, int STEP, int LAG>
+int wave_launch_fast(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a, hipStream_t st) {
+    return p->set->bytes > kStreamBytes ? wave_launch_fast_nt<W, SIZE, STEP, LAG, true>(h, p, a, st)
+                                        : wave_launch_fast_nt<W, SIZE, STEP, LAG, false>(h, p, a, st);
 }
 
 }  // namespace

@@ -78,6 +78,22 @@ __device__ __forceinline__ void wave_stamp(const WaveArgs &a, int slot) {
     }
 }
 
+// Sequence bytes are read once per pass (plus a 4 % halo): a non-temporal load (global_load ... nt)
+// streams them past the caches' retention policy.  A pure read of this shape runs at 7.06 TB/s with
+// it and 6.3 TB/s without (tools/stream_read.hip, profiles/r02_stream_read.txt).  A batch small enough
+// to stay in L2 / the Infinity Cache between passes keeps plain loads (NT = false): the 12-Mb pass is
+// 8 % slower with the hint, the 120-Mb and 384-Mb passes 4-5 % faster.
+template <bool NT>
+__device__ __forceinline__ uint4 load_stream16(const uint4 *p) {
+    if constexpr (NT) {
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
+        return make_uint4(t.x, t.y, t.z, t.w);
+    } else {
+        return *p;
+    }
+}
+
 // ---- G/C/g/c classification of 16 packed bytes -> 16-bit mask ------------------
 // 'C' 0x43, 'G' 0x47, 'c' 0x63, 'g' 0x67 are exactly the bytes with
 // (b & 0xDB) == 0x43 (0xDB drops the case bit 0x20 and the C/G bit 0x04), i.e.
@@ -453,7 +469,7 @@ __device__ __forceinline__ void z_decide(float nf, float kkf, float S1f, float S
 // Interleaved A/B (tools/ab.py) on 384 Mb: W = 12 runs 115 -> 105 us with the cap.
 // SIZE/STEP/LAG != 0 bake the headline parameters into the instruction stream (constant
 // bit-field offsets in phase 2); 0 = taken from the arguments at run time.
-template <int W, int SIZE, int STEP, int LAG>
+template <int W, int SIZE, int STEP, int LAG, bool NT>
 // `tiles` and `seq` are kernel parameters of their own, in front of the argument block: with
 // -mllvm -amdgpu-kernarg-preload-count the command processor delivers the first kernel-argument
 // dwords in SGPRs at wave start, so the tile descriptor's load does not wait for a scalar load of
@@ -506,11 +522,11 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveTile *const
         constexpr uint32_t NLD = (NCH + 255u) / 256u;
         uint4 v[NLD];
 #pragma unroll
-        for (uint32_t k = 0; k + 1u < NLD; ++k) v[k] = src[tid + 256u * k];
+        for (uint32_t k = 0; k + 1u < NLD; ++k) v[k] = load_stream16<NT>(src + tid + 256u * k);
         // the last row is only partly inside the largest tile: lanes past it skip the load
         // (issued last, so the predicated block delays no other load)
         v[NLD - 1u] = make_uint4(0, 0, 0, 0);
-        if (tid + 256u * (NLD - 1u) < NCH) v[NLD - 1u] = src[tid + 256u * (NLD - 1u)];
+        if (tid + 256u * (NLD - 1u) < NCH) v[NLD - 1u] = load_stream16<NT>(src + tid + 256u * (NLD - 1u));
 #pragma unroll
         for (uint32_t k = 0; k < NLD; ++k) BM[tid + 256u * k] = (uint16_t)gc_mask16(v[k]);
     } else
@@ -522,10 +538,10 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveTile *const
         const uint32_t last = nchunk - 1u;
         uint4 cur[4], nxt[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) cur[k] = src[min(tid + 256u * k, last)];
+        for (int k = 0; k < 4; ++k) cur[k] = load_stream16<NT>(src + min(tid + 256u * k, last));
         for (uint32_t c0 = tid; c0 < nchunk; c0 += 1024u) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) nxt[k] = src[min(c0 + 1024u + 256u * k, last)];
+            for (int k = 0; k < 4; ++k) nxt[k] = load_stream16<NT>(src + min(c0 + 1024u + 256u * k, last));
 #pragma unroll
             for (int k = 0; k < 4; ++k) BM[min(c0 + 256u * k, nchunk)] = (uint16_t)gc_mask16(cur[k]);
 #pragma unroll

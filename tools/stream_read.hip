@@ -17,13 +17,21 @@
     } while (0)
 
 // one tile per workgroup: ROWS back-to-back 16-B loads per thread, xor-reduced
-template <int ROWS, int OCC>
+template <int ROWS, int OCC, bool NT = false>
 __global__ __launch_bounds__(256, OCC) void tile_read(const uint4 *src, unsigned *sink, unsigned lds_pad) {
     extern __shared__ unsigned pad[];
     const uint4 *p = src + (size_t)blockIdx.x * (ROWS * 256) + threadIdx.x;
     uint4 v[ROWS];
 #pragma unroll
-    for (int k = 0; k < ROWS; ++k) v[k] = p[256 * k];
+    for (int k = 0; k < ROWS; ++k) {
+        if (NT) {
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+            const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p + 256 * k));
+            v[k] = make_uint4(t.x, t.y, t.z, t.w);
+        } else {
+            v[k] = p[256 * k];
+        }
+    }
     unsigned x = 0;
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) x ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
@@ -76,10 +84,11 @@ double time_us(F launch, int reps) {
     return ms * 1e3 / reps;
 }
 
-template <int ROWS, int OCC>
+template <int ROWS, int OCC, bool NT = false>
 void run_tile(const uint4 *d, unsigned *sink, size_t bytes, unsigned lds) {
     const unsigned n_tiles = (unsigned)(bytes / (ROWS * 4096));
-    auto k = tile_read<ROWS, OCC>;
+    if (NT) printf("(nontemporal) ");
+    auto k = tile_read<ROWS, OCC, NT>;
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const double us = time_us([&] { hipLaunchKernelGGL(k, dim3(n_tiles), dim3(256), lds, 0, d, sink, lds); }, 20);
     printf("tile_read  rows=%2d (%3d KiB/wg) occ<=%d lds=%6u  %8.1f us  %7.1f GB/s\n", ROWS, ROWS * 4, OCC, lds, us,
@@ -108,6 +117,8 @@ int main(int argc, char **argv) {
     run_tile<2, 8>(d, sink, bytes, 0);
     run_tile<4, 8>(d, sink, bytes, 0);
     run_tile<8, 8>(d, sink, bytes, 0);
+    run_tile<8, 8, true>(d, sink, bytes, 0);
+    run_tile<4, 8, true>(d, sink, bytes, 0);
     run_tile<8, 8>(d, sink, bytes, 40 * 1024);   // 4 workgroups per CU (LDS bound)
     run_tile<8, 8>(d, sink, bytes, 80 * 1024);   // 2 per CU
     run_tile<8, 4>(d, sink, bytes, 0);
