@@ -284,6 +284,10 @@ def main():
             if nb == 1:
                 p.set_depth((args.depth or 2) if on else 1)
             p.set_lane(j % 4 if on and nb > 1 else 0)
+            # tapered launches (smaller tiles at the end of the tile table) shorten the tail of a launch
+            # that runs alone; with passes in flight the tails overlap and the small tiles are only extra
+            # work, so a host that keeps batches in flight turns them off (gams_wave_plan_set_taper)
+            p.set_taper(0 if on else -1)
 
     def barrier():
         eng.sync()
@@ -369,6 +373,8 @@ def main():
                 "peaks_per_step": [int(p.size) for p in peaks],
                 "exact_path_windows_per_rotation": int(n_exact),
                 "passes_in_flight": (min(nb, 4) if nb > 1 else (args.depth or 2)) if in_flight else 1,
+                "tapered_launches": "off in the timed region (passes in flight), on in the roofline leg (one pass at a time)"
+                                    if in_flight else "on",
                 "clock_ramp_ms": args.ramp_ms,
                 "clock_ramp_steps": ramp_steps,
                 "windows_per_s_one_pass_at_a_time": serial_windows / (launch_ms * 1e-3),

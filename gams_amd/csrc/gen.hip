@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void gen_scan_kernel(const uint8_t *seq, uint6
                                                        unsigned long long *n_flips) {
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
-    const uint4 v = reinterpret_cast<const uint4 *>(seq)[c];
+    const uint4 v = load_once16(reinterpret_cast<const uint4 *>(seq) + c);   // a chromosome is scanned once
     uint32_t m = valid_mask16(v);
     const uint64_t b0 = c * 16u;
     if (b0 + 16u > len) m &= (1u << (uint32_t)(len - b0)) - 1u;      // tail of the sequence

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void gc_index_build(const uint8_t *seq, uint64
         const uint64_t c = c0 + lc;
         uint32_t m = 0;
         if (c < n_chunks) {
-            const uint4 v = src[c];
+            const uint4 v = load_once16(src + c);   // the index is built in one pass over the sequence
             m = gc_nibble(v.x) | (gc_nibble(v.y) << 4) | (gc_nibble(v.z) << 8) | (gc_nibble(v.w) << 12);
         }
         msk[lc + (lc >> 8)] = m;  // +1 word per 256: thread t's 16-word run starts on bank 17t

@@ -86,6 +86,8 @@ struct gams_wave_plan {
     Way way[gams_gpu::kMaxWays];
     uint32_t depth = 1;                         // ways in use
     uint32_t lane = 0;                          // way k runs on stream (lane + k) % kMaxWays (gams_wave_plan_set_lane)
+    int taper_req = -1;                         // gams_wave_plan_set_taper: -1 auto, 0 off, 1 on
+    bool taper = false;                         // the tile table ends in W = 8 and W = 4 tiles (wave_fast_taper_kernel)
     uint32_t last_way = 0;                      // way of the most recent run
     uint32_t sel_age = 0;                       // readers look at the run `sel_age` before the most recent one
     hipEvent_t ready = nullptr;                 // recorded on the compute stream behind the const table
@@ -202,12 +204,33 @@ void wave_fill_tiles(gams_wave_plan_t *p) {
     }
 }
 
+// Tapered tile table for the baked W = 12 kernel: the ctgs holding the last windows of the batch are
+// cut into W = 4 tiles, the ones before them into W = 8 tiles (see wave_fast_taper_kernel).  The two
+// tails are half a round of workgroup slots each, and at most 8 % / 17 % of the batch.
+void wave_fill_tiles_tapered(gams_wave_plan_t *p, uint32_t slots) {
+    const gams_wave_params_t &q = p->prm;
+    const uint32_t tw12 = 256u * 12u - q.lag - 1u, tw8 = 256u * 8u - q.lag - 1u, tw4 = 256u * 4u - q.lag - 1u;
+    const uint64_t T = p->total_windows;
+    const uint64_t x4 = std::min<uint64_t>((uint64_t)(slots / 2) * tw4, T * 8 / 100);
+    const uint64_t y8 = std::min<uint64_t>((uint64_t)(slots / 2) * tw8, T * 17 / 100);
+    p->tiles.clear();
+    for (uint32_t c = 0; c < p->set->n_ctg; ++c) {
+        const uint32_t n = p->ctgs[c].n_win;
+        const uint64_t after = T - p->ctgs[c].win_base;           // windows from this ctg's first to the end of the batch
+        const uint32_t w_kind = after <= x4 ? 4u : after <= x4 + y8 ? 8u : 12u;
+        const uint32_t tw = w_kind == 4u ? tw4 : w_kind == 8u ? tw8 : tw12;
+        for (uint32_t w = 0; w < n; w += tw)
+            p->tiles.push_back(WaveTile{c, w, n, w_kind, p->ctgs[c].seq_off, p->ctgs[c].win_base});
+    }
+}
+
 int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
     const gams_wave_params_t &q = p->prm;
     const uint64_t halo_bytes = (uint64_t)(q.lag + 1) * q.step + (uint64_t)q.size + 32;
     p->fast_w = 0;
     p->attr_set = false;
     p->direct = false;
+    p->taper = false;
     // fast kernel: 8-bit counts, 32-bit variance math with 24-bit multiplies
     const bool fast_ok = !p->serial && q.size <= 255 && q.step <= 32 && (uint64_t)q.lag * q.size <= 65535 &&
                          (uint64_t)q.lag * q.size * q.size < (1ull << 24) && q.lag >= 2;
@@ -250,7 +273,16 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
             p->k16 = false;
             p->wide = false;
             p->lds_bytes = wave_fast_lds_bytes(p->max_chunks, (uint32_t)pick, q.lag, (p->flags & GAMS_WAVE_DENSE) != 0);
-            wave_fill_tiles(p);
+            // a launch of at least a round and a half of workgroups ends in smaller tiles, unless the host
+            // keeps passes in flight (their tails overlap anyway, and the small tiles cost 3-4 % more work)
+            const uint32_t slots = 8u * (uint32_t)std::max(h->cus, 1);
+            const bool headline = q.size == 100 && q.step == 10 && q.lag == 100;
+            const bool want = p->taper_req < 0 ? p->depth == 1 : p->taper_req != 0;
+            p->taper = want && tw_req == 0 && pick == 12 && headline && p->total_windows / p->tw >= slots + slots / 2;
+            if (p->taper)
+                wave_fill_tiles_tapered(p, slots);
+            else
+                wave_fill_tiles(p);
             return GAMS_OK;
         }
     }
@@ -419,6 +451,19 @@ template <int W, int SIZE, int STEP, int LAG>
 int wave_launch_fast(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a, hipStream_t st) {
     return p->set->bytes > kStreamBytes ? wave_launch_fast_nt<W, SIZE, STEP, LAG, true>(h, p, a, st)
                                         : wave_launch_fast_nt<W, SIZE, STEP, LAG, false>(h, p, a, st);
+}
+
+template <bool NT>
+int wave_launch_taper(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a, hipStream_t st) {
+    auto kern = wave_fast_taper_kernel<100, 10, 100, NT>;
+    if (!p->attr_set) {
+        GAMS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+        p->attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)p->tiles.size()), dim3(256), p->lds_bytes, st, a.tiles, a.seq, a);
+    GAMS_HIP(h, hipGetLastError());
+    return GAMS_OK;
 }
 
 }  // namespace
@@ -649,6 +694,8 @@ static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
         ;   // counted and decided above
     else if (p->fast_w == 20)
         rc = baked ? wave_launch_fast<20, 100, 1, 100>(h, p, a, st) : wave_launch_fast<20, 0, 0, 0>(h, p, a, st);
+    else if (p->taper)
+        rc = p->set->bytes > kStreamBytes ? wave_launch_taper<true>(h, p, a, st) : wave_launch_taper<false>(h, p, a, st);
     else if (p->fast_w == 12)
         rc = !baked ? wave_launch_fast<12, 0, 0, 0>(h, p, a, st)
              : step1 ? wave_launch_fast<12, 100, 1, 100>(h, p, a, st)
@@ -876,6 +923,25 @@ int gams_wave_plan_set_depth(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t depth)
     rc = wave_build_geometry(h, p, p->tw_req);      // the default tile depends on the depth
     if (rc != GAMS_OK) return rc;
     (void)hipFree(p->d_stamps);                     // sized for the old tiling
+    p->d_stamps = nullptr;
+    rc = wave_upload_geometry(h, p);
+    if (rc == GAMS_OK) rc = wave_alloc_ways(h, p);
+    return rc;
+}
+
+int gams_wave_plan_set_taper(gams_gpu_t *h, gams_wave_plan_t *p, int mode) {
+    if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_plan_set_taper: null argument");
+    if (mode < -1 || mode > 1) return gams_fail(h, GAMS_EINVAL, "wave_plan_set_taper: mode must be -1 (auto), 0 or 1");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    int rc = wave_sync_ways(h, p);
+    if (rc != GAMS_OK) return rc;
+    p->taper_req = mode;
+    const bool before = p->taper;
+    rc = wave_build_geometry(h, p, p->tw_req);
+    if (rc != GAMS_OK) return rc;
+    if (p->taper == before) return GAMS_OK;       // same tile table
+    p->ran = false;
+    (void)hipFree(p->d_stamps);
     p->d_stamps = nullptr;
     rc = wave_upload_geometry(h, p);
     if (rc == GAMS_OK) rc = wave_alloc_ways(h, p);

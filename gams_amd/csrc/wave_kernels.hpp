@@ -474,8 +474,7 @@ template <int W, int SIZE, int STEP, int LAG, bool NT>
 // -mllvm -amdgpu-kernarg-preload-count the command processor delivers the first kernel-argument
 // dwords in SGPRs at wave start, so the tile descriptor's load does not wait for a scalar load of
 // the arguments first (two dependent round trips before a workgroup's first sequence load -> one).
-__global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveTile *const tiles_p, const uint8_t *const seq_p,
-                                                           const WaveArgs a) {
+__device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t *const seq_p, const WaveArgs &a) {
     static_assert(W % 4 == 0 && (((W / 4) & 1) == 1 || W == 8), "W/4 odd (LDS bank stride), or W = 8 (64-bit reads)");
     static_assert((SIZE == 0) == (STEP == 0) && (SIZE == 0) == (LAG == 0), "bake all three or none");
     // Windows per tile.  Baked parameters: 256*W - LAG - 1, so that the tile's K slots (its windows
@@ -495,7 +494,6 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveTile *const
     uint8_t *SG = reinterpret_cast<uint8_t *>(PS + 272);
 
     const uint32_t tid = threadIdx.x;
-    const WaveTile tl = tiles_p[blockIdx.x];         // issued before anything waits for the argument block
     if (a.stamps != nullptr && threadIdx.x == 0)
         a.stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();  // workgroup entry
     const struct { uint64_t seq_off, win_base; uint32_t n_win; } cg = {tl.seq_off, tl.win_base, tl.n_win};
@@ -893,6 +891,30 @@ __global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveTile *const
         }
     }
     wave_stamp(a, 6);
+}
+
+template <int W, int SIZE, int STEP, int LAG, bool NT>
+__global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveTile *const tiles_p, const uint8_t *const seq_p,
+                                                           const WaveArgs a) {
+    const WaveTile tl = tiles_p[blockIdx.x];         // issued before anything waits for the argument block
+    wave_fast_tile<W, SIZE, STEP, LAG, NT>(tl, seq_p, a);
+}
+
+// Tapered launch (baked parameters): the tile table ends in tiles of 8 and then 4 windows per thread
+// (WaveTile::pad = W of the tile; all tiles of a ctg have one size).  Workgroups are dispatched in
+// blockIdx order, so the launch ends in short-lived workgroups: its tail -- the time the last
+// workgroups load and compute alone, ~10 us of a 28-us launch over 120 Mb -- shrinks to the life of
+// a W = 4 tile, for 3-4 % more work (the small tiles carry relatively more halo).
+template <int SIZE, int STEP, int LAG, bool NT>
+__global__ __launch_bounds__(256, 8) void wave_fast_taper_kernel(const WaveTile *const tiles_p,
+                                                                 const uint8_t *const seq_p, const WaveArgs a) {
+    const WaveTile tl = tiles_p[blockIdx.x];
+    if (tl.pad == 12u)
+        wave_fast_tile<12, SIZE, STEP, LAG, NT>(tl, seq_p, a);
+    else if (tl.pad == 8u)
+        wave_fast_tile<8, SIZE, STEP, LAG, NT>(tl, seq_p, a);
+    else
+        wave_fast_tile<4, SIZE, STEP, LAG, NT>(tl, seq_p, a);
 }
 
 // ---- parameters whose halo does not fit a tile (large step or lag): no tiling ---------------

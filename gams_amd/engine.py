@@ -136,6 +136,10 @@ class WavePlan:
         """run this plan on HIP stream `lane` (+ way) of the handle: plans on different lanes overlap"""
         self.eng.check(self.eng.lib.gams_wave_plan_set_lane(self.eng.h, self.p, lane))
 
+    def set_taper(self, mode):
+        """-1 auto (on for depth 1), 0 off (passes in flight), 1 on: the launch ends in smaller tiles"""
+        self.eng.check(self.eng.lib.gams_wave_plan_set_taper(self.eng.h, self.p, mode))
+
     def select(self, age):
         """point peaks()/dense()/exact_count() at the run `age` runs before the most recent one"""
         self.eng.check(self.eng.lib.gams_wave_plan_select(self.eng.h, self.p, age))

@@ -138,6 +138,13 @@ int gams_wave_plan_select(gams_gpu_t *h, gams_wave_plan_t *plan, uint32_t age);
  * overlap on the device exactly like the ways of one plan; the readers wait for their own plan only.
  * Call while the plan is idle (it waits for the plan's queued runs). */
 int gams_wave_plan_set_lane(gams_gpu_t *h, gams_wave_plan_t *plan, uint32_t lane);
+/* Tapered launches.  A launch of the headline parameters (size 100, step 10, lag 100) over at least a
+ * round and a half of workgroups ends in smaller tiles (the ctgs holding the last 17 % / 8 % of the
+ * windows are cut into tiles of 2/3 and 1/3 the size), so that its last workgroups are short-lived and
+ * the chip drains in ~3 instead of ~10 us; the small tiles cost 3-4 % more work.  mode -1 (default):
+ * on for plans of depth 1; 0: off -- what a host wants that keeps several passes in flight (plans on
+ * lanes, or depth > 1): their tails overlap anyway; 1: on.  Results are identical either way. */
+int gams_wave_plan_set_taper(gams_gpu_t *h, gams_wave_plan_t *plan, int mode);
 /* Pipelined plans record an event behind every run, and gams_wave_peaks / gams_wave_dense wait
  * for that run only (so a host can keep several plans in flight on one handle: upload of batch
  * k+1 and its kernel overlap the readback and formatting of batch k).  Off by default: the

@@ -238,3 +238,35 @@ def test_config3_grch38_step1_sharded_over_eight_handles(eng):
         got = whole[first[i]:first[i + 1]].copy()
         got["ctg"] = 0
         assert np.array_equal(got, rec), i
+
+
+def test_tapered_launch_equals_plain(eng):
+    """gams_wave_plan_set_taper: the same genome with the tile table ending in W = 8 / W = 4 tiles (default for a
+    plan of depth 1 over at least a round and a half of workgroups), without them, and with passes in flight:
+    identical peak records (and the oracle's, through test_config2 above)."""
+    ctgs = synth.genome_ctgs(synth.ATHA_LENGTHS, 500000)
+    ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])
+    plan = engine.WavePlan(eng, ss, 100, 10, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS)
+    plan.run()
+    tapered = plan.peaks()
+    n_exact = plan.exact_count()
+    plan.set_taper(0)
+    plan.run()
+    plain = plan.peaks()
+    assert np.array_equal(tapered, plain)
+    # (which windows take the exact path depends on the tiling: the guard band uses a per-thread bound on S1)
+    assert abs(plan.exact_count() - n_exact) <= 0.2 * n_exact
+    plan.set_taper(1)
+    plan.set_depth(3)
+    plan.run_n(7)
+    for age in range(3):
+        plan.select(age)
+        assert np.array_equal(plan.peaks(), plain), age
+    plan.set_depth(1)
+    plan.set_taper(-1)
+    plan.run()
+    assert np.array_equal(plan.peaks(), plain)
+    with pytest.raises(_lib.GamsError):
+        plan.set_taper(2)
+    plan.close()
+    ss.close()
