@@ -206,13 +206,17 @@ void wave_fill_tiles(gams_wave_plan_t *p) {
 
 // Tapered tile table for the baked W = 12 kernel: the ctgs holding the last windows of the batch are
 // cut into W = 4 tiles, the ones before them into W = 8 tiles (see wave_fast_taper_kernel).  The two
-// tails are half a round of workgroup slots each, and at most 8 % / 17 % of the batch.
+// tails are a quarter / half a round of workgroup slots, and at most 8 % / 17 % of the batch.
 void wave_fill_tiles_tapered(gams_wave_plan_t *p, uint32_t slots) {
     const gams_wave_params_t &q = p->prm;
     const uint32_t tw12 = 256u * 12u - q.lag - 1u, tw8 = 256u * 8u - q.lag - 1u, tw4 = 256u * 4u - q.lag - 1u;
     const uint64_t T = p->total_windows;
-    const uint64_t x4 = std::min<uint64_t>((uint64_t)(slots / 2) * tw4, T * 8 / 100);
-    const uint64_t y8 = std::min<uint64_t>((uint64_t)(slots / 2) * tw8, T * 17 / 100);
+    // measurement knobs: % of a round of workgroup slots for the W = 4 / W = 8 tails (gpurun_out/r2_taper_sweep.log:
+    // 384 Mb 71.6 us without tails, 70.0 at 50/50, 68.5 at 25/50, 70.9 at 100/100; the 120-Mb launch 28.4-28.7 for all)
+    static const int k4 = [] { const char *e = getenv("GAMS_TAPER4"); return e ? atoi(e) : 25; }();
+    static const int k8 = [] { const char *e = getenv("GAMS_TAPER8"); return e ? atoi(e) : 50; }();
+    const uint64_t x4 = std::min<uint64_t>((uint64_t)slots * k4 / 100 * tw4, T * 8 / 100);
+    const uint64_t y8 = std::min<uint64_t>((uint64_t)slots * k8 / 100 * tw8, T * 17 / 100);
     p->tiles.clear();
     for (uint32_t c = 0; c < p->set->n_ctg; ++c) {
         const uint32_t n = p->ctgs[c].n_win;
