@@ -3,7 +3,7 @@
 # Kernel trace + stats of `python3 bench.py <args>` (one pass at a time, so that the per-kernel average
 # is the launch duration bench.py's roofline block reports), then PMC passes in their own runs
 # (never combined with trace domains), then gpurun_out/prof_<tag>/{kernel_stats.csv,wave_pmc.json}.
-# <grid-filter>: only dispatches of wave_fast_kernel with this Grid_Size enter wave_pmc.json (0 = all).
+# <grid-filter>: only dispatches of the wave_fast kernels with this Grid_Size enter wave_pmc.json (0 = all).
 set -o pipefail
 TAG=$1; GRID=$2; shift; shift
 export TMPDIR=/tmp
@@ -30,7 +30,7 @@ grids = collections.Counter()
 for d in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"):
     for f in glob.glob(f"{out}/{d}/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            if "wave_fast_kernel" not in r["Kernel_Name"]:
+            if "wave_fast" not in r["Kernel_Name"]:
                 continue
             grids[(r["Kernel_Name"].split("(")[0][-40:], r.get("Grid_Size", "?"))] += 1
             if grid != "0" and r.get("Grid_Size") != grid:
