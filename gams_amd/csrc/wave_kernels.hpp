@@ -521,10 +521,11 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
         uint4 v[NLD];
 #pragma unroll
         for (uint32_t k = 0; k + 1u < NLD; ++k) v[k] = load_stream16<NT>(src + tid + 256u * k);
-        // the last row is only partly inside the largest tile: lanes past it skip the load
-        // (issued last, so the predicated block delays no other load)
-        v[NLD - 1u] = make_uint4(0, 0, 0, 0);
-        if (tid + 256u * (NLD - 1u) < NCH) v[NLD - 1u] = load_stream16<NT>(src + tid + 256u * (NLD - 1u));
+        // the last row is only partly inside the largest tile: lanes past it re-read the tile's last
+        // chunk (one more request for the same line; their masks land behind the tile's last chunk in
+        // BM, where nothing reads).  Unconditional: a predicated load sits in its own basic block and
+        // makes hipcc wait vmcnt(0) right behind it -- which the tapered kernel's inlined bodies did.
+        v[NLD - 1u] = load_stream16<NT>(src + min(tid + 256u * (NLD - 1u), NCH - 1u));
 #pragma unroll
         for (uint32_t k = 0; k < NLD; ++k) BM[tid + 256u * k] = (uint16_t)gc_mask16(v[k]);
     } else
