@@ -445,10 +445,12 @@ def main():
             g = synth.genome_ctgs(lengths, piece, first_chr_index=500 if tag == "synth384" else 1)
             ss = engine.SeqSet(eng, [c["seq"] for c in g])
             plan = engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS, tile_windows=args.tile, **prm)
-            for _ in range(20):
-                plan.run()
-            eng.sync()
-            reps = 200 if tag == "S288c" else 20
+            t_r = time.perf_counter()                      # time-based ramp here too: 20 launches are 0.15-1.4 ms
+            while (time.perf_counter() - t_r) * 1e3 < 30.0:
+                for _ in range(50):
+                    plan.run()
+                eng.sync()
+            reps = 200 if tag == "S288c" else 40
             eng.timer_start()
             for _ in range(reps):
                 plan.run()

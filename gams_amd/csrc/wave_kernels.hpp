@@ -519,13 +519,19 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
         constexpr uint32_t NCH = ((uint32_t)TW * STEP + ((uint32_t)LAG + 1u) * STEP + SIZE + 30u) / 16u + 1u;
         constexpr uint32_t NLD = (NCH + 255u) / 256u;
         uint4 v[NLD];
+        // The tile's first row holds the halo (the previous tile's last 1.1 KB) and its last row the bytes
+        // the next tile will want as ITS halo: those two rows are read with plain loads -- the last one leaves
+        // its lines in the caches, the first one finds them there -- and the rows in between with the streaming
+        // hint.  384-Mb launch: 70.4 us all streaming, 69.4 first row plain, 70.9 last row plain, 67.1 both
+        // (gpurun_out/r2_ab12.log); the two-round 120-Mb launch does not care (27.2-27.4 us).
+        v[0] = load_stream16<false>(src + tid);
 #pragma unroll
-        for (uint32_t k = 0; k + 1u < NLD; ++k) v[k] = load_stream16<NT>(src + tid + 256u * k);
+        for (uint32_t k = 1; k + 1u < NLD; ++k) v[k] = load_stream16<NT>(src + tid + 256u * k);
         // the last row is only partly inside the largest tile: lanes past it re-read the tile's last
         // chunk (one more request for the same line; their masks land behind the tile's last chunk in
         // BM, where nothing reads).  Unconditional: a predicated load sits in its own basic block and
         // makes hipcc wait vmcnt(0) right behind it -- which the tapered kernel's inlined bodies did.
-        v[NLD - 1u] = load_stream16<NT>(src + min(tid + 256u * (NLD - 1u), NCH - 1u));
+        v[NLD - 1u] = load_stream16<false>(src + min(tid + 256u * (NLD - 1u), NCH - 1u));
 #pragma unroll
         for (uint32_t k = 0; k < NLD; ++k) BM[tid + 256u * k] = (uint16_t)gc_mask16(v[k]);
     } else
