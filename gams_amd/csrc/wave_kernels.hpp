@@ -444,24 +444,29 @@ __device__ __forceinline__ void z_decide(float nf, float kkf, float S1f, float S
 }
 
 // =============================================================================
-// wave_fast_kernel<W,SIZE,STEP,LAG>: the tile algorithm for 8-bit counts (size <= 255),
-// step <= 32 and 32-bit variance math (lag*size <= 65535, lag*size^2 < 2^24), i.e. every
-// BASELINE configuration.  256 threads, W windows per thread, tile = 256*W windows.
+// wave_fast_tile<W,SIZE,STEP,LAG,NT>: the tile algorithm for 8-bit counts (size <= 255),
+// step <= 32 and 24-bit sums (lag*size <= 65535, lag*size^2 < 2^24), i.e. every BASELINE
+// configuration.  256 threads, W windows per thread; a tile holds 256*W - lag - 1 windows when the
+// parameters are baked in, 256*W otherwise.  wave_fast_kernel runs one tile size per launch,
+// wave_fast_taper_kernel W = 12 tiles followed by W = 8 and W = 4 tiles (the launch's tail).
 //
-//   phase 1  tile bytes HBM -> registers (16 B/lane, coalesced) -> G/C/g/c flags
-//            (v_bitop3, v_add, v_bitop3 per dword; v_dot4 gathers 4 flags) -> 16-bit mask
-//            per 16-B chunk -> LDS bit stream BM (1 bit per base).
+//   phase 1  tile bytes HBM -> registers (16 B/lane, coalesced; NT: the first and last row with
+//            plain loads -- they hold / leave the halo -- the rows between with the streaming hint)
+//            -> G/C/g/c flags (v_bitop3, v_add, v_bitop3 per dword; v_dot4 gathers 4 flags) ->
+//            16-bit mask per 16-B chunk -> LDS bit stream BM (1 bit per base).
 //   phase 2  window counts, rolling over the bit stream: k(w+1) = k(w) + popc(step bits
 //            entering) - popc(step bits leaving); stored as bytes K[].  Slot idx holds
 //            window vb+idx with vb = w0-lag-1; windows before the ctg start read as 0.
-//   phase 3  thread t owns windows w0 + t*W + [0,W).  It sums the lag counts in front of
-//            its first window once (v_dot4 on packed bytes: S1 = sum k, S2 = sum k^2) and
-//            then rolls: S(q+1) = S(q) - K[tW+q] + K[tW+q+lag].  All K traffic is whole
-//            dwords at an odd dword stride between lanes (W/4 in {1,3,5}): conflict-free.
-//            Branch-free integer decision; three sign bits per window are shifted into
-//            accumulators with v_alignbit.  Window i == lag (averages [0,lag): stat.rs:30-31) is redone by
-//            its owner.  Windows inside the guard band: const_sig table (homopolymer runs)
-//            or exact_signal_wave.
+//            Baked: every thread owns W slots and also leaves their (sum k, sum k^2) in PS[].
+//   phase 3  thread t owns windows w0 + t*W + [0,W).  S1 = sum k, S2 = sum k^2 over the lag
+//            counts in front of its first window: lag / W blocks of PS + lag % W counts of K
+//            (baked), or v_dot4 over the packed bytes; then rolled in f32 (exact): S(q+1) =
+//            S(q) - K[tW+q] + K[tW+q+lag].  K traffic is whole dwords at an odd dword stride
+//            between lanes (W/4 in {1,3,5}): conflict-free.  Branch-free decision in the squared
+//            domain (z_decide: no sqrt, no int<->float conversion); three sign bits per window are
+//            shifted into accumulators with v_alignbit.  Window i == lag (averages [0,lag):
+//            stat.rs:30-31) is redone by its owner.  Windows inside the guard band: const_sig
+//            table (homopolymer runs) or exact_signal_wave.
 //   phase 4  dense rows through LDS (coalesced stores) and/or per-thread peak counts ->
 //            one workgroup scan -> records in window order into the tile's fixed slot.
 // =============================================================================
