@@ -20,14 +20,15 @@ else:
     ctgs = synth.genome_ctgs(synth.S288C_LENGTHS, 500000)
 ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])
 tw = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-plan = engine.WavePlan(eng, ss, 100, 10, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS, tile_windows=tw)
+step = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+plan = engine.WavePlan(eng, ss, 100, step, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS, tile_windows=tw)
 for _ in range(5):
     plan.run()
 eng.sync()
 eng.check(eng.lib.gams_wave_plan_set_stamps(eng.h, plan.p, 1))
 plan.run()
 eng.sync()
-nt = 20000
+nt = 120000
 buf = np.zeros(nt * 16, np.uint64)
 eng.check(eng.lib.gams_wave_stamps_raw(eng.h, plan.p, buf.ctypes.data, buf.size))
 st = buf.reshape(-1, 16)
