@@ -342,6 +342,7 @@ def main():
     kernel_ms = eng.timer_stop()      # HIP events on the library's compute stream
     eng.sync()
     launch_ms = kernel_ms / serial_steps
+    kernel_name = plans[0].kernel_name()   # the instantiation this leg launched (rocprofv3's row of the same name)
     serial_windows = sum(win_per_batch[i % nb] for i in range(serial_steps)) / serial_steps
 
     out = None
@@ -384,7 +385,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "wave_fast_kernel",
+                "kernel": kernel_name,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",

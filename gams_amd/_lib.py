@@ -61,6 +61,7 @@ PROTOTYPES = {
     "gams_wave_plan_select": (C.c_int, [_VP, _VP, C.c_uint32]),
     "gams_wave_plan_set_lane": (C.c_int, [_VP, _VP, C.c_uint32]),
     "gams_wave_plan_set_taper": (C.c_int, [_VP, _VP, C.c_int]),
+    "gams_wave_plan_kernel_name": (C.c_int, [_VP, _VP, C.c_char_p, C.c_size_t]),
     "gams_wave_plan_set_pipelined": (C.c_int, [_VP, _VP, C.c_int]),
     "gams_wave_run": (C.c_int, [_VP, _VP]),
     "gams_wave_peaks": (C.c_int, [_VP, _VP, _PP, C.POINTER(C.c_uint64)]),

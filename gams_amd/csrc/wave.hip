@@ -952,6 +952,28 @@ int gams_wave_plan_set_taper(gams_gpu_t *h, gams_wave_plan_t *p, int mode) {
     return rc;
 }
 
+int gams_wave_plan_kernel_name(gams_gpu_t *h, gams_wave_plan_t *p, char *buf, size_t n) {
+    if (!h || !p || !buf || n == 0) return gams_fail(h, GAMS_EINVAL, "wave_plan_kernel_name: null argument");
+    // the same decisions as wave_pass_on_way, spelled the way rocprofv3 prints the instantiation
+    const gams_wave_params_t &q = p->prm;
+    const bool baked = p->fast_w && wave_is_baked(q, p->fast_w);
+    const char *nt = p->set->bytes > kStreamBytes ? "true" : "false";
+    std::string name;
+    if (p->serial)
+        name = q.lag + 1u <= kSerialRing ? "wave_serial_wave_kernel" : "wave_serial_kernel";
+    else if (p->direct)
+        name = "wave_direct_count_kernel + wave_direct_signal_kernel";
+    else if (p->taper)
+        name = std::string("wave_fast_taper_kernel<100, 10, 100, ") + nt + ">";
+    else if (p->fast_w) {
+        const std::string prm = baked ? "100, " + std::to_string(q.step) + ", 100, " : "0, 0, 0, ";
+        name = "wave_fast_kernel<" + std::to_string(p->fast_w) + ", " + prm + nt + ">";
+    } else
+        name = std::string("wave_tile_kernel<") + (p->k16 ? "unsigned short, " : "unsigned char, ") + (p->wide ? "true>" : "false>");
+    std::snprintf(buf, n, "%s", name.c_str());
+    return GAMS_OK;
+}
+
 int gams_wave_plan_set_lane(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t lane) {
     if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_plan_set_lane: null argument");
     if (lane >= (uint32_t)gams_gpu::kMaxWays)

@@ -140,6 +140,12 @@ class WavePlan:
         """-1 auto (on for depth 1), 0 off (passes in flight), 1 on: the launch ends in smaller tiles"""
         self.eng.check(self.eng.lib.gams_wave_plan_set_taper(self.eng.h, self.p, mode))
 
+    def kernel_name(self):
+        """the kernel that does this plan's work, as rocprofv3 --kernel-trace names it (gams_wave_plan_kernel_name)"""
+        buf = C.create_string_buffer(160)
+        self.eng.check(self.eng.lib.gams_wave_plan_kernel_name(self.eng.h, self.p, buf, len(buf)))
+        return buf.value.decode()
+
     def select(self, age):
         """point peaks()/dense()/exact_count() at the run `age` runs before the most recent one"""
         self.eng.check(self.eng.lib.gams_wave_plan_select(self.eng.h, self.p, age))

@@ -145,6 +145,11 @@ int gams_wave_plan_set_lane(gams_gpu_t *h, gams_wave_plan_t *plan, uint32_t lane
  * on for plans of depth 1; 0: off -- what a host wants that keeps several passes in flight (plans on
  * lanes, or depth > 1): their tails overlap anyway; 1: on.  Results are identical either way. */
 int gams_wave_plan_set_taper(gams_gpu_t *h, gams_wave_plan_t *plan, int mode);
+/* Name of the kernel that does the plan's work, spelled as rocprofv3 --kernel-trace prints the
+ * instantiation (without the namespace), e.g. "wave_fast_taper_kernel<100, 10, 100, true>": lets a
+ * benchmark line name the row of the profile its launch duration must agree with.  Follows the plan's
+ * current settings (set_tile / set_taper / the seqset's size).  NUL-terminated, truncated to n. */
+int gams_wave_plan_kernel_name(gams_gpu_t *h, gams_wave_plan_t *plan, char *buf, size_t n);
 /* Pipelined plans record an event behind every run, and gams_wave_peaks / gams_wave_dense wait
  * for that run only (so a host can keep several plans in flight on one handle: upload of batch
  * k+1 and its kernel overlap the readback and formatting of batch k).  Off by default: the

@@ -247,10 +247,12 @@ def test_tapered_launch_equals_plain(eng):
     ctgs = synth.genome_ctgs(synth.ATHA_LENGTHS, 500000)
     ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])
     plan = engine.WavePlan(eng, ss, 100, 10, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS)
+    assert plan.kernel_name() == "wave_fast_taper_kernel<100, 10, 100, true>"   # 120 MB > 64 MB: streaming loads
     plan.run()
     tapered = plan.peaks()
     n_exact = plan.exact_count()
     plan.set_taper(0)
+    assert plan.kernel_name() == "wave_fast_kernel<12, 100, 10, 100, true>"
     plan.run()
     plain = plan.peaks()
     assert np.array_equal(tapered, plain)

@@ -575,3 +575,20 @@ def test_influence_recurrence_one_wave_per_ctg(eng, s288c, lag, infl, thr):
         assert np.array_equal(pk[pk["ctg"] == c]["window"], idx)
     plan.close()
     ss.close()
+
+
+def test_plan_kernel_name_follows_the_plan(eng):
+    """gams_wave_plan_kernel_name spells the instantiation the plan launches (the row rocprofv3 prints)."""
+    seq = synth(300_000, 77)
+    ss = engine.SeqSet(eng, [seq])
+    names = {}
+    for prm in [(100, 10, 100, 1.0), (100, 1, 100, 1.0), (50, 7, 33, 1.0), (100, 10, 100, 0.5), (100, 1000, 100, 1.0)]:
+        plan = engine.WavePlan(eng, ss, prm[0], prm[1], prm[2], 3.0, prm[3], flags=_lib.WAVE_PEAKS)
+        names[prm] = plan.kernel_name()
+        plan.close()
+    ss.close()
+    assert names[(100, 10, 100, 1.0)] == "wave_fast_kernel<12, 100, 10, 100, false>"     # one round of tiles: no taper
+    assert names[(100, 1, 100, 1.0)] == "wave_fast_kernel<20, 100, 1, 100, false>"
+    assert names[(50, 7, 33, 1.0)].startswith("wave_fast_kernel<") and ", 0, 0, 0, false>" in names[(50, 7, 33, 1.0)]
+    assert names[(100, 10, 100, 0.5)] == "wave_serial_wave_kernel"
+    assert names[(100, 1000, 100, 1.0)].startswith("wave_direct_count_kernel")
