@@ -34,6 +34,29 @@ void put_str(std::string &o, const std::string &s) {   // String: u64 length + U
     o += s;
 }
 
+// std::str::from_utf8: shortest forms only, no surrogates, nothing above U+10FFFF
+bool valid_utf8(const uint8_t *b, size_t n) {
+    for (size_t i = 0; i < n;) {
+        const uint8_t c = b[i];
+        size_t k;
+        uint32_t lo;
+        if (c < 0x80) { ++i; continue; }
+        if (c >= 0xC2 && c <= 0xDF) { k = 1; lo = 0x80; }
+        else if (c >= 0xE0 && c <= 0xEF) { k = 2; lo = 0x800; }
+        else if (c >= 0xF0 && c <= 0xF4) { k = 3; lo = 0x10000; }
+        else return false;
+        if (n - i <= k) return false;
+        uint32_t cp = c & (0x3Fu >> k);
+        for (size_t j = 1; j <= k; ++j) {
+            if ((b[i + j] & 0xC0) != 0x80) return false;
+            cp = (cp << 6) | (b[i + j] & 0x3Fu);
+        }
+        if (cp < lo || cp > 0x10FFFF || (cp >= 0xD800 && cp <= 0xDFFF)) return false;
+        i += k + 1;
+    }
+    return true;
+}
+
 struct Reader {
     const uint8_t *p;
     size_t n, at = 0;
@@ -62,6 +85,9 @@ struct Reader {
         const uint64_t len = u64();
         if (len > n - at) throw Error(GAMS_EINVAL, "bincode: string length " + std::to_string(len) + " beyond the input");
         std::string s(reinterpret_cast<const char *>(p + at), (size_t)len);
+        // a Rust String: bincode's deserializer refuses bytes that are not UTF-8 ("invalid utf-8 encoding")
+        if (!valid_utf8(p + at, (size_t)len))
+            throw Error(GAMS_EINVAL, "bincode: string at offset " + std::to_string(at) + " is not UTF-8");
         at += (size_t)len;
         return s;
     }

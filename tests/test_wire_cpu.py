@@ -59,6 +59,21 @@ def test_ctg_bundle_rejects_unsorted_keys_and_huge_lengths():
         host.bincode_ctg_bundle_decode(struct.pack("<QQ", 1, 2**40) + b"xx")
 
 
+@pytest.mark.parametrize("raw,ok", [(b"ctg:\xce\xb1:1", True), (b"ctg:\xe2\x82\xac:1", True), (b"ctg:\xf0\x9f\xa7\xac:1", True),
+                                    (b"ctg:\xff:1", False), (b"ctg:\xc0\xaf:1", False), (b"ctg:\xed\xa0\x80:1", False),
+                                    (b"ctg:\xf4\x90\x80\x80:1", False), (b"ctg:\xe2\x82", False), (b"ctg:\x80:1", False)])
+def test_bincode_strings_must_be_utf8(raw, ok):
+    """a Rust String: bincode 1.3.3 deserialises it through str::from_utf8 (shortest forms, no surrogates,
+    <= U+10FFFF) and fails with "invalid utf-8 encoding" otherwise; the decoders here do the same."""
+    blob = struct.pack("<Q", 1) + struct.pack("<II", 5, 9) + struct.pack("<Q", len(raw)) + raw
+    blob += struct.pack("<QI", 1, 5) + struct.pack("<QI", 1, 9) + struct.pack("<I", 4) + b"\x00\x00"
+    if ok:
+        assert raw.decode() in host.bincode_lapper_decode(blob)
+    else:
+        with pytest.raises(host.HostError):
+            host.bincode_lapper_decode(blob)
+
+
 def lapper_bytes(ivs):
     ivs = sorted(ivs, key=lambda v: (v[0], v[1]))                                # Lapper::new: intervals.sort(), stable
     out = struct.pack("<Q", len(ivs)) + b"".join(struct.pack("<II", a, b) + s(v) for a, b, v in ivs)
