@@ -183,7 +183,7 @@ void wave_squared_band(const gams_wave_params_t &p, const float g[4], float sq[6
 bool wave_is_baked(const gams_wave_params_t &q, int w) {
     const bool headline = q.size == 100 && q.step == 10 && q.lag == 100;   // every BASELINE step-10 config
     const bool step1 = q.size == 100 && q.step == 1 && q.lag == 100;       // BASELINE configs[3] (GRCh38, step 1)
-    return (headline && (w == 12 || w == 8 || w == 4)) || (step1 && (w == 20 || w == 12));
+    return (headline && (w == 12 || w == 8 || w == 4)) || (step1 && (w == 28 || w == 20 || w == 12));
 }
 
 size_t wave_fast_lds_bytes(uint32_t max_chunks, uint32_t w, uint32_t lag, bool dense) {
@@ -191,6 +191,7 @@ size_t wave_fast_lds_bytes(uint32_t max_chunks, uint32_t w, uint32_t lag, bool d
     b += 16 * 4;                                         // scratch
     b += (256u * w + lag + 1u + 31u) & ~15u;             // K (threads past the tile's end still read their slots)
     b += 272 * 8;                                        // PS: block sums of the baked kernels
+    b += 256 * 2;                                        // RK: ranks of phase 4b
     if (dense) b += (256u * w + 15u) & ~15u;             // SG
     return (b + 15) & ~(size_t)15;
 }
@@ -238,8 +239,10 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
     // fast kernel: 8-bit counts, 32-bit variance math with 24-bit multiplies
     const bool fast_ok = !p->serial && q.size <= 255 && q.step <= 32 && (uint64_t)q.lag * q.size <= 65535 &&
                          (uint64_t)q.lag * q.size * q.size < (1ull << 24) && q.lag >= 2;
-    if (fast_ok && (tw_req == 0 || tw_req == 1024 || tw_req == 2048 || tw_req == 3072 || tw_req == 5120)) {
-        static const int cand[4] = {20, 12, 8, 4};
+    const bool step1_prm = q.size == 100 && q.step == 1 && q.lag == 100;
+    if (fast_ok && (tw_req == 0 || tw_req == 1024 || tw_req == 2048 || tw_req == 3072 || tw_req == 5120 ||
+                    (tw_req == 7168 && step1_prm))) {
+        static const int cand[5] = {28, 20, 12, 8, 4};
         int pick = 0;
         for (int w : cand) {
             const uint64_t tw = 256ull * w;
@@ -257,11 +260,13 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
             //   2.4 M          11.3 / 10.4 / 11.0  |  5.76 / 4.35 / 4.07
             //   3.6 M          15.0 / 14.2 / 14.2  |  8.42 / 6.44 / 5.91
             //   38 M (384 Mb)   107 /   82 /   77
-            // W = 20 for the baked step-1 kernel (measured 452 vs 503 us on 3.8e8 windows), otherwise
+            // W = 28 / 20 for the baked step-1 kernel (3.8e8 windows: 320 us at W = 28, 334 at W = 20, 503 at
+            // W = 12 in round 1; 1.2e7 windows, less than a round of W = 28 tiles: 23.5 vs 21.0 us), otherwise
             // only on request.
             const uint64_t tiles = p->total_windows / tw;
             const bool step1 = q.size == 100 && q.step == 1 && q.lag == 100;   // baked W = 20 fits 64 VGPRs
             const bool flight = p->depth >= 2;
+            if (pick == 0 && w == 28 && step1 && tiles >= 4096) pick = w;
             if (pick == 0 && w == 20 && step1 && tiles >= 1024) pick = w;
             if (pick == 0 && w == 12 && tiles >= (flight ? 768u : 1536u)) pick = w;
             if (pick == 0 && w == 8 && tiles >= (flight ? 512u : 1024u)) pick = w;
@@ -696,6 +701,8 @@ static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
     const bool step1 = baked && q.step == 1;
     if (p->direct)
         ;   // counted and decided above
+    else if (p->fast_w == 28)
+        rc = wave_launch_fast<28, 100, 1, 100>(h, p, a, st);   // baked only (wave_build_geometry)
     else if (p->fast_w == 20)
         rc = baked ? wave_launch_fast<20, 100, 1, 100>(h, p, a, st) : wave_launch_fast<20, 0, 0, 0>(h, p, a, st);
     else if (p->taper)

@@ -480,7 +480,7 @@ template <int W, int SIZE, int STEP, int LAG, bool NT>
 // dwords in SGPRs at wave start, so the tile descriptor's load does not wait for a scalar load of
 // the arguments first (two dependent round trips before a workgroup's first sequence load -> one).
 __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t *const seq_p, const WaveArgs &a) {
-    static_assert(W % 4 == 0 && (((W / 4) & 1) == 1 || W == 8), "W/4 odd (LDS bank stride), or W = 8 (64-bit reads)");
+    static_assert(W % 4 == 0 && W <= 28 && (((W / 4) & 1) == 1 || W == 8), "W/4 odd (LDS bank stride), or W = 8 (64-bit reads); one mask bit per window");
     static_assert((SIZE == 0) == (STEP == 0) && (SIZE == 0) == (LAG == 0), "bake all three or none");
     // Windows per tile.  Baked parameters: 256*W - LAG - 1, so that the tile's K slots (its windows
     // plus the lag+1 in front) are exactly 256*W: every thread of phase 2 owns W slots, which are
@@ -496,7 +496,8 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
     const uint32_t *KW = reinterpret_cast<const uint32_t *>(K);
     // PS[t] = (sum k, sum k^2) over K slots [t*W, t*W + W)   (baked kernels; 256 + 16 entries)
     uint2 *PS = reinterpret_cast<uint2 *>(K + ((256u * W + (LAG ? (uint32_t)LAG : a.lag) + 1u + 31u) & ~15u));
-    uint8_t *SG = reinterpret_cast<uint8_t *>(PS + 272);
+    uint16_t *RK = reinterpret_cast<uint16_t *>(PS + 272);   // phase 4b (W > 12): a thread's rank inside its wave
+    uint8_t *SG = reinterpret_cast<uint8_t *>(RK + 256);
 
     const uint32_t tid = threadIdx.x;
     if (a.stamps != nullptr && threadIdx.x == 0)
@@ -877,9 +878,9 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
 
     // ---- phase 4b: ordered compaction: record order == window order -----------------------
     // W <= 12 (step 10: a thread holds at most a few peaks): every thread writes its own records at
-    // its rank in the tile.  W = 20 (step 1, where a GC crest spans 10-30 adjacent windows, i.e. one
-    // or two threads hold all of a wave's peaks and that loop runs 20 times with 62 lanes idle):
-    // every thread publishes (window mask, rank inside its wave) in LDS and the tile's records are
+    // its rank in the tile.  W >= 20 (step 1, where a GC crest spans 10-30 adjacent windows, i.e. one
+    // or two threads hold all of a wave's peaks and that loop runs W times with 62 lanes idle):
+    // every thread publishes its window masks and its rank inside its wave in LDS and the tile's records are
     // dealt out one per thread -- record r finds its wave (three compares with the wave totals), its
     // owner (six-step search over the wave's ranks), its window (the n-th set bit of the owner's
     // mask) and stores 16 B next to its neighbours': a fixed ~80 instructions per 256 records.
@@ -912,12 +913,12 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
                 }
             }
         } else {
-            static_assert(W <= 20, "the window mask (W bits) and the rank in the wave (11 bits) share one word");
             const uint32_t inc = wave_incl_scan(mine);
             if ((tid & 63u) == 63u) scr[tid >> 6] = inc;
             __syncthreads();                               // every wave is past phase 3: PS can be reused
             uint2 *const MB = PS;
-            MB[tid] = make_uint2(both | ((inc - mine) << 20), crest);
+            MB[tid] = make_uint2(both, crest);
+            RK[tid] = (uint16_t)(inc - mine);              // < 64 * W
             const uint32_t c1 = scr[0], c2 = c1 + scr[1], c3 = c2 + scr[2], tot = c3 + scr[3];
             __syncthreads();
             if (tid == 0) a.tile_cnt[blockIdx.x] = tot;
@@ -927,13 +928,12 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
                 const uint32_t rl = r - (r >= c3 ? c3 : r >= c2 ? c2 : r >= c1 ? c1 : 0u);
                 // the last thread of wave wr whose rank is <= rl (ranks do not decrease; a thread without
                 // peaks shares its rank with its successor, so the last one is the owner)
-                const uint32_t key = (rl + 1u) << 20;
                 uint32_t t = wr * 64u;
 #pragma unroll
                 for (uint32_t s = 32u; s != 0u; s >>= 1)
-                    if (MB[t + s].x < key) t += s;
+                    if (RK[t + s] <= rl) t += s;
                 const uint2 m = MB[t];
-                uint32_t n = rl - (m.x >> 20), msk = m.x & 0xFFFFFu, q = 0;
+                uint32_t n = rl - RK[t], msk = m.x, q = 0;
 #pragma unroll
                 for (uint32_t s = 16u; s != 0u; s >>= 1) {  // n-th set bit: skip the low s bits while they hold <= n
                     const uint32_t c = (uint32_t)__popc(msk & ((1u << s) - 1u));

@@ -132,6 +132,10 @@ class WavePlan:
         """passes in flight: consecutive run() calls rotate over `depth` streams and output sets"""
         self.eng.check(self.eng.lib.gams_wave_plan_set_depth(self.eng.h, self.p, depth))
 
+    def set_tile(self, tile_windows):
+        """windows per workgroup (0: the library's choice); 1024 / 2048 / 3072 / 5120 / 7168 select the fast kernels' W"""
+        self.eng.check(self.eng.lib.gams_wave_plan_set_tile(self.eng.h, self.p, tile_windows))
+
     def set_lane(self, lane):
         """run this plan on HIP stream `lane` (+ way) of the handle: plans on different lanes overlap"""
         self.eng.check(self.eng.lib.gams_wave_plan_set_lane(self.eng.h, self.p, lane))

@@ -87,7 +87,7 @@ def test_config3_step1_geometry_one_chromosome(eng):
     assert n > 59_000_000
     exp = oracle_peaks(ctgs, 100, 1, 100, 3.0)
     assert np.array_equal(pk, exp)
-    for tile in (1024, 5120, 4096):
+    for tile in (1024, 5120, 7168, 4096):          # W = 4, 20, 28 (the default here), the general kernel
         other, _ = gpu_peaks(eng, ss, 100, 1, 100, 3.0, tile)
         assert np.array_equal(other, pk), tile
     ss.close()

@@ -314,9 +314,10 @@ def test_run_n_equals_repeated_run(eng, s288c, depth, n):
 
 
 @pytest.mark.parametrize("prm", [(100, 10, 100, 3.0), (100, 1, 100, 3.0), (50, 7, 33, 2.0), (255, 8, 60, 1.0)])
-@pytest.mark.parametrize("tile", [1024, 2048, 3072, 5120])
+@pytest.mark.parametrize("tile", [1024, 2048, 3072, 5120, 7168])
 def test_every_fast_tile_size_matches_the_oracle(eng, s288c, prm, tile):
-    """W = 4 / 8 / 12 / 20 windows per thread (tile 1024 / 2048 / 3072 / 5120), baked and run-time parameters."""
+    """W = 4 / 8 / 12 / 20 / 28 windows per thread (tile 1024 / 2048 / 3072 / 5120 / 7168; W = 28 exists for
+    the baked step-1 parameters only, elsewhere 7168 is a tile of the general kernel), baked and run-time parameters."""
     seqs = [bytes(s288c["I"]), synth(33333, 3).tobytes(), bytes(s288c["Mito"][:20000])]
     ss = engine.SeqSet(eng, seqs)
     try:
@@ -585,10 +586,21 @@ def test_plan_kernel_name_follows_the_plan(eng):
     for prm in [(100, 10, 100, 1.0), (100, 1, 100, 1.0), (50, 7, 33, 1.0), (100, 10, 100, 0.5), (100, 1000, 100, 1.0)]:
         plan = engine.WavePlan(eng, ss, prm[0], prm[1], prm[2], 3.0, prm[3], flags=_lib.WAVE_PEAKS)
         names[prm] = plan.kernel_name()
+        if prm == (100, 10, 100, 1.0):
+            plan.set_tile(3072)
+            names["headline, 3072"] = plan.kernel_name()
+        if prm == (100, 1, 100, 1.0):
+            for tw in (5120, 7168):
+                plan.set_tile(tw)
+                names[f"step 1, {tw}"] = plan.kernel_name()
         plan.close()
     ss.close()
-    assert names[(100, 10, 100, 1.0)] == "wave_fast_kernel<12, 100, 10, 100, false>"     # one round of tiles: no taper
-    assert names[(100, 1, 100, 1.0)] == "wave_fast_kernel<20, 100, 1, 100, false>"
-    assert names[(50, 7, 33, 1.0)].startswith("wave_fast_kernel<") and ", 0, 0, 0, false>" in names[(50, 7, 33, 1.0)]
+    # a 300-kb ctg is a handful of tiles: the smallest tile, which is baked for the headline parameters only
+    assert names[(100, 10, 100, 1.0)] == "wave_fast_kernel<4, 100, 10, 100, false>"
+    assert names["headline, 3072"] == "wave_fast_kernel<12, 100, 10, 100, false>"
+    assert names[(100, 1, 100, 1.0)] == "wave_fast_kernel<4, 0, 0, 0, false>"
+    assert names["step 1, 5120"] == "wave_fast_kernel<20, 100, 1, 100, false>"
+    assert names["step 1, 7168"] == "wave_fast_kernel<28, 100, 1, 100, false>"
+    assert names[(50, 7, 33, 1.0)] == "wave_fast_kernel<4, 0, 0, 0, false>"
     assert names[(100, 10, 100, 0.5)] == "wave_serial_wave_kernel"
     assert names[(100, 1000, 100, 1.0)].startswith("wave_direct_count_kernel")
