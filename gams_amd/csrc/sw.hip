@@ -151,12 +151,23 @@ __device__ __forceinline__ float round4(float x) {  // utils.rs:135-138 with dec
     return roundf(x * y) / y;
 }
 
+// one selected ctg of a batched sw call
+struct SwCtg {
+    uint64_t seq_off;     // buffer offset of ctg base 0
+    uint32_t len;
+    int32_t chr_start, chr_end;
+    uint32_t feat_first;  // index of the ctg's first feature in the call's feature arrays
+    uint32_t pad[2];
+};
+
 struct SwArgs {
     const uint32_t *pm;
     const uint64_t *seg;
-    uint64_t seq_off;   // buffer offset of ctg base 0
+    uint64_t seq_off;   // buffer offset of ctg base 0   (sw_kernel: filled per thread from ctgs[])
     uint32_t len;
     int32_t chr_start, chr_end;
+    const SwCtg *ctgs;        // sw_kernel: the selected ctgs
+    const uint32_t *fctg;     // sw_kernel: selected-ctg number of every feature
     const int32_t *fs, *fe;
     const uint64_t *row_off;  // exclusive prefix of rows per feature
     uint32_t nf;
@@ -184,12 +195,20 @@ __device__ __forceinline__ uint64_t gc_prefix_at(const SwArgs &a, int64_t b) {
 }
 
 // one thread per (feature, slot); slot 0 = M, 1..max = L, max+1..2max = R
-__global__ __launch_bounds__(256) void sw_kernel(const SwArgs a) {
+// All selected ctgs of a call in ONE launch (a ctg's ~400 features are a handful of workgroups: launched
+// per ctg the kernel is all launch latency).
+__global__ __launch_bounds__(256) void sw_kernel(const SwArgs a0) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t slots = 1u + 2u * (uint32_t)a.max;
+    const uint32_t slots = 1u + 2u * (uint32_t)a0.max;
     const uint64_t f = gid / slots;
     const uint32_t slot = (uint32_t)(gid % slots);
-    if (f >= a.nf) return;
+    if (f >= a0.nf) return;
+    const SwCtg cg = a0.ctgs[a0.fctg[f]];
+    SwArgs a = a0;
+    a.seq_off = cg.seq_off;
+    a.len = cg.len;
+    a.chr_start = cg.chr_start;
+    a.chr_end = cg.chr_end;
     const SwGeom g = sw_geometry(a.chr_start, a.chr_end, a.fs[f], a.fe[f], a.size, a.max);
     int32_t type, dist, ws, we;
     uint64_t row = a.row_off[f];
@@ -215,7 +234,7 @@ __global__ __launch_bounds__(256) void sw_kernel(const SwArgs a) {
     }
     if (row >= a.cap) return;
     gams_sw_row_t r;
-    r.feature = (uint32_t)f;
+    r.feature = (uint32_t)f - cg.feat_first;
     r.type = type;
     r.distance = dist;
     r.start = ws;
@@ -328,93 +347,138 @@ void gams_seqset_gcindex_free(gams_seqset_t *s) {
     s->gcindex = nullptr;
 }
 
-extern "C" int gams_gpu_sw(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, int32_t chr_start,
-                           const int32_t *feat_start, const int32_t *feat_end, uint32_t nf, int32_t size,
-                           int32_t max, int32_t resize, gams_sw_row_t *rows, uint64_t cap, uint64_t *n_rows) {
-    if (!h || !s || !n_rows || (nf && (!feat_start || !feat_end)))
+extern "C" int gams_gpu_sw_batch(gams_gpu_t *h, gams_seqset_t *s, uint32_t n_sel, const uint32_t *ctg_index,
+                                 const int32_t *chr_start, const uint64_t *feat_off, const int32_t *feat_start,
+                                 const int32_t *feat_end, int32_t size, int32_t max, int32_t resize,
+                                 gams_sw_row_t *rows, uint64_t cap, uint64_t *row_off, uint64_t *n_rows) {
+    if (!h || !s || !n_rows || (n_sel && (!ctg_index || !chr_start || !feat_off)))
         return gams_fail(h, GAMS_EINVAL, "gpu_sw: null argument");
-    if (i >= s->n_ctg) return gams_fail(h, GAMS_EINVAL, "gpu_sw: ctg index out of range");
     // size or resize 1: half_resize = 0 makes center_resize slice [mid+1, mid-1] (window.rs:113-123),
     // an empty span whose min()/max() the reference then asks for -- no defined answer to mirror
     if (size < 2 || max < 0 || resize < 2)
         return gams_fail(h, GAMS_EINVAL, "gpu_sw: size >= 2, max >= 0, resize >= 2 (center_resize of 1 bp is an empty span)");
-    if (s->len[i] == 0 || s->len[i] > 0x7fffffffu) return gams_fail(h, GAMS_EINVAL, "gpu_sw: ctg length out of range");
-    GAMS_HIP(h, hipSetDevice(h->device));
     *n_rows = 0;
-    if (nf == 0) return GAMS_OK;
-    int rc = gams_seqset_gcindex(h, s);
-    if (rc != GAMS_OK) return rc;
-    const int32_t chr_end = chr_start + (int32_t)s->len[i] - 1;
-    // rows per feature in closed form (window.rs:29-41) -> exclusive offsets
-    std::vector<uint64_t> off(nf + 1);
+    if (row_off)
+        for (uint32_t k = 0; k <= n_sel; ++k) row_off[k] = 0;
+    if (n_sel == 0) return GAMS_OK;
+    if (feat_off[0] != 0) return gams_fail(h, GAMS_EINVAL, "gpu_sw: feat_off[0] must be 0");
+    for (uint32_t k = 0; k < n_sel; ++k) {
+        if (ctg_index[k] >= s->n_ctg) return gams_fail(h, GAMS_EINVAL, "gpu_sw: ctg index out of range");
+        if (feat_off[k + 1] < feat_off[k]) return gams_fail(h, GAMS_EINVAL, "gpu_sw: feat_off must not decrease");
+        const uint32_t len = s->len[ctg_index[k]];
+        if (len == 0 || len > 0x7fffffffu) return gams_fail(h, GAMS_EINVAL, "gpu_sw: ctg length out of range");
+    }
+    const uint64_t nf64 = feat_off[n_sel];
+    if (nf64 == 0) return GAMS_OK;
+    if (!feat_start || !feat_end) return gams_fail(h, GAMS_EINVAL, "gpu_sw: null argument");
+    const uint64_t threads = nf64 * (1u + 2u * (uint64_t)max);
+    if (nf64 > 0xffffffffull || (threads + 255) / 256 > 0x7fffffffull)
+        return gams_fail(h, GAMS_EUNSUPPORTED, "gpu_sw: too many feature slots for one launch");
+    const uint32_t nf = (uint32_t)nf64;
+    GAMS_HIP(h, hipSetDevice(h->device));
+
+    // Inputs are assembled in one page-locked block (one DMA): ctgs | fs | fe | fctg | off; the rows per
+    // feature come from the closed form (window.rs:29-41) -> exclusive offsets.
+    const size_t b_ctg = ((size_t)n_sel * sizeof(SwCtg) + 255) & ~(size_t)255;
+    const size_t b_i32 = ((size_t)nf * sizeof(int32_t) + 255) & ~(size_t)255;
+    const size_t b_off = (((size_t)nf + 1) * sizeof(uint64_t) + 255) & ~(size_t)255;
+    const size_t in_bytes = b_ctg + 3 * b_i32 + b_off;
+    const bool size_query = !rows || cap == 0;
+    uint8_t *pin = nullptr, *dev = nullptr;
+    size_t pin_cap = 0, dev_cap = 0;
+    std::vector<uint64_t> off_host;                 // size query: no device, no pinned memory
+    uint64_t *off = nullptr;
+    SwCtg *cg = nullptr;
+    int32_t *fs = nullptr, *fe = nullptr;
+    uint32_t *fctg = nullptr;
+    if (size_query) {
+        off_host.resize((size_t)nf + 1);
+        off = off_host.data();
+    } else {
+        const hipError_t e = gams_pool_alloc(h, true, in_bytes, reinterpret_cast<void **>(&pin), &pin_cap);
+        if (e != hipSuccess) return gams_fail(h, GAMS_ENOMEM, std::string("gpu_sw: pinned staging: ") + hipGetErrorString(e));
+        cg = reinterpret_cast<SwCtg *>(pin);
+        fs = reinterpret_cast<int32_t *>(pin + b_ctg);
+        fe = reinterpret_cast<int32_t *>(pin + b_ctg + b_i32);
+        fctg = reinterpret_cast<uint32_t *>(pin + b_ctg + 2 * b_i32);
+        off = reinterpret_cast<uint64_t *>(pin + b_ctg + 3 * b_i32);
+    }
+    auto release = [&]() {
+        if (pin) gams_pool_free(h, true, pin, pin_cap);
+        if (dev) gams_pool_free(h, false, dev, dev_cap);
+    };
     uint64_t tot = 0;
-    for (uint32_t f = 0; f < nf; ++f) {
-        off[f] = tot;
-        {
+    for (uint32_t k = 0; k < n_sel; ++k) {
+        const uint32_t i = ctg_index[k];
+        const int32_t cs = chr_start[k], ce = cs + (int32_t)s->len[i] - 1;
+        if (row_off) row_off[k] = tot;
+        if (cg) cg[k] = SwCtg{s->off[i], s->len[i], cs, ce, (uint32_t)feat_off[k], {0u, 0u}};
+        for (uint64_t f = feat_off[k]; f < feat_off[k + 1]; ++f) {
             // window.rs:98-110: the middle pair of the feature must be members of the ctg span --
             // IntSpan::index of a non-member has no defined answer in the reference to mirror
             const int64_t flen = (int64_t)feat_end[f] - feat_start[f] + 1, half = flen / 2;
             const int64_t mid_l = half == 0 ? feat_start[f] : (int64_t)feat_start[f] + half - 1;
             const int64_t mid_r = half == 0 ? feat_start[f] : (int64_t)feat_start[f] + half;
-            if (flen < 1 || mid_l < chr_start || mid_r > chr_end)
-                return gams_fail(h, GAMS_EINVAL,
-                                 "gpu_sw: feature " + std::to_string(f) + " is empty or has its middle outside the ctg");
+            if (flen < 1 || mid_l < cs || mid_r > ce) {
+                release();
+                return gams_fail(h, GAMS_EINVAL, "gpu_sw: feature " + std::to_string(f - feat_off[k]) +
+                                                     (n_sel > 1 ? " of selected ctg " + std::to_string(k) : std::string()) +
+                                                     " is empty or has its middle outside the ctg");
+            }
+            off[f] = tot;
+            const SwGeom g = sw_geometry(cs, ce, feat_start[f], feat_end[f], size, max);
+            tot += 1u + (uint64_t)g.n_l + (uint64_t)g.n_r;
+            if (fs) {
+                fs[f] = feat_start[f];
+                fe[f] = feat_end[f];
+                fctg[f] = k;
+            }
         }
-        const SwGeom g = sw_geometry(chr_start, chr_end, feat_start[f], feat_end[f], size, max);
-        tot += 1u + (uint64_t)g.n_l + (uint64_t)g.n_r;
     }
     off[nf] = tot;
+    if (row_off) row_off[n_sel] = tot;
     *n_rows = tot;
-    if (!rows || cap == 0) return GAMS_OK;  // size query
+    if (size_query) return GAMS_OK;
+
+    int rc = gams_seqset_gcindex(h, s);
+    if (rc != GAMS_OK) {
+        release();
+        return rc;
+    }
     const uint64_t n_out = std::min<uint64_t>(tot, cap);
-    int32_t *d_fs = nullptr, *d_fe = nullptr;
-    uint64_t *d_off = nullptr;
-    gams_sw_row_t *d_rows = nullptr;
-    auto cleanup = [&]() {
-        (void)hipFree(d_fs);
-        (void)hipFree(d_fe);
-        (void)hipFree(d_off);
-        (void)hipFree(d_rows);
-    };
+    const size_t b_rows = (size_t)std::max<uint64_t>(n_out, 1) * sizeof(gams_sw_row_t);
+    hipError_t e = gams_pool_alloc(h, false, in_bytes + b_rows, reinterpret_cast<void **>(&dev), &dev_cap);
+    if (e != hipSuccess) {
+        release();
+        return gams_fail(h, GAMS_ENOMEM, std::string("gpu_sw: device buffers: ") + hipGetErrorString(e));
+    }
 #define SW_HIP(call)                                                                   \
     do {                                                                               \
         hipError_t e_ = (call);                                                        \
         if (e_ != hipSuccess) {                                                        \
-            cleanup();                                                                 \
+            (void)hipStreamSynchronize(h->compute);                                    \
+            release();                                                                 \
             return gams_fail(h, GAMS_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
         }                                                                              \
     } while (0)
-    SW_HIP(hipMalloc(&d_fs, nf * sizeof(int32_t)));
-    SW_HIP(hipMalloc(&d_fe, nf * sizeof(int32_t)));
-    SW_HIP(hipMalloc(&d_off, (nf + 1) * sizeof(uint64_t)));
-    SW_HIP(hipMalloc(&d_rows, std::max<uint64_t>(n_out, 1) * sizeof(gams_sw_row_t)));
-    SW_HIP(hipMemcpyAsync(d_fs, feat_start, nf * sizeof(int32_t), hipMemcpyHostToDevice, h->compute));
-    SW_HIP(hipMemcpyAsync(d_fe, feat_end, nf * sizeof(int32_t), hipMemcpyHostToDevice, h->compute));
-    SW_HIP(hipMemcpyAsync(d_off, off.data(), (nf + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, h->compute));
+    SW_HIP(hipMemcpyAsync(dev, pin, in_bytes, hipMemcpyHostToDevice, h->compute));
+    gams_sw_row_t *d_rows = reinterpret_cast<gams_sw_row_t *>(dev + in_bytes);
     SwArgs a{};
     a.pm = s->gcindex->d_pm;
     a.seg = s->gcindex->d_seg;
-    a.seq_off = s->off[i];
-    a.len = s->len[i];
-    a.chr_start = chr_start;
-    a.chr_end = chr_end;
-    a.fs = d_fs;
-    a.fe = d_fe;
-    a.row_off = d_off;
+    a.ctgs = reinterpret_cast<const SwCtg *>(dev);
+    a.fs = reinterpret_cast<const int32_t *>(dev + b_ctg);
+    a.fe = reinterpret_cast<const int32_t *>(dev + b_ctg + b_i32);
+    a.fctg = reinterpret_cast<const uint32_t *>(dev + b_ctg + 2 * b_i32);
+    a.row_off = reinterpret_cast<const uint64_t *>(dev + b_ctg + 3 * b_i32);
     a.nf = nf;
     a.size = size;
     a.max = max;
     a.resize = resize;
     a.rows = d_rows;
     a.cap = n_out;
-    const uint64_t threads = (uint64_t)nf * (1u + 2u * (uint64_t)max);
-    const uint64_t blocks = (threads + 255) / 256;
-    if (blocks > 0x7fffffffull) {
-        cleanup();
-        return gams_fail(h, GAMS_EUNSUPPORTED, "gpu_sw: too many feature slots for one launch");
-    }
     SW_HIP(hipEventRecord(h->k0, h->compute));
-    hipLaunchKernelGGL(sw_kernel, dim3((unsigned)blocks), dim3(256), 0, h->compute, a);
+    hipLaunchKernelGGL(sw_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, h->compute, a);
     SW_HIP(hipGetLastError());
     SW_HIP(hipEventRecord(h->k1, h->compute));
     h->k_valid = true;
@@ -422,8 +486,18 @@ extern "C" int gams_gpu_sw(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, int32_t 
     SW_HIP(hipMemcpyAsync(rows, d_rows, n_out * sizeof(gams_sw_row_t), hipMemcpyDeviceToHost, h->compute));
     SW_HIP(hipStreamSynchronize(h->compute));
 #undef SW_HIP
-    cleanup();
+    release();
     return GAMS_OK;
+}
+
+extern "C" int gams_gpu_sw(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, int32_t chr_start,
+                           const int32_t *feat_start, const int32_t *feat_end, uint32_t nf, int32_t size,
+                           int32_t max, int32_t resize, gams_sw_row_t *rows, uint64_t cap, uint64_t *n_rows) {
+    if (!h || !s || !n_rows || (nf && (!feat_start || !feat_end)))
+        return gams_fail(h, GAMS_EINVAL, "gpu_sw: null argument");
+    const uint64_t feat_off[2] = {0, nf};
+    return gams_gpu_sw_batch(h, s, 1, &i, &chr_start, feat_off, feat_start, feat_end, size, max, resize, rows, cap,
+                             nullptr, n_rows);
 }
 
 // gc_content (round4) of arbitrary chromosome ranges inside ctg i: gams::cache_gc_content

@@ -477,8 +477,19 @@ std::vector<std::string> sw_proc_ctgs_multi(const std::vector<gams_gpu_t *> &han
     const std::vector<uint32_t> owner = lpt_assign(weight, (uint32_t)handles.size());
     std::vector<std::string> out(ctgs.size());
     run_shares((uint32_t)handles.size(), [&](uint32_t d) {
+        std::vector<Ctg> dc;
+        std::vector<const uint8_t *> ds;
+        std::vector<std::vector<Feature>> df;
+        std::vector<size_t> where;
         for (size_t c = 0; c < ctgs.size(); ++c)
-            if (owner[c] == d && !features[c].empty()) out[c] = sw_proc_ctg(handles[d], ctgs[c], seqs[c], features[c], a);
+            if (owner[c] == d && !features[c].empty()) {
+                dc.push_back(ctgs[c]);
+                ds.push_back(seqs[c]);
+                df.push_back(features[c]);
+                where.push_back(c);
+            }
+        std::vector<std::string> rows = sw_proc_ctgs(handles[d], dc, ds, df, a);
+        for (size_t k = 0; k < where.size(); ++k) out[where[k]] = std::move(rows[k]);
     });
     return out;
 }
@@ -624,26 +635,10 @@ std::vector<std::string> wave_proc_ctgs_multi(const std::vector<gams_gpu_t *> &h
 // ---------------------------------------------------------------------------
 // sw
 // ---------------------------------------------------------------------------
-std::string sw_proc_ctg(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq, const std::vector<Feature> &features,
-                        const SwArgs &a) {
-    std::string out;
-    const uint32_t nf = (uint32_t)features.size();
-    if (nf == 0) return out;
-    uint32_t len = (uint32_t)(ctg.chr_end - ctg.chr_start + 1);
-    SeqSetGuard sg{h};
-    check(h, gams_seqset_create(h, 1, &len, &sg.s));
-    check(h, gams_seqset_upload(h, sg.s, 0, seq));
-    std::vector<int32_t> fs(nf), fe(nf);
-    for (uint32_t f = 0; f < nf; ++f) {
-        fs[f] = features[f].start;
-        fe[f] = features[f].end;
-    }
-    uint64_t nrows = 0;
-    check(h, gams_gpu_sw(h, sg.s, 0, ctg.chr_start, fs.data(), fe.data(), nf, a.size, a.max, a.resize, nullptr, 0,
-                         &nrows));
-    std::vector<gams_sw_row_t> rows(nrows ? nrows : 1);
-    check(h, gams_gpu_sw(h, sg.s, 0, ctg.chr_start, fs.data(), fe.data(), nf, a.size, a.max, a.resize,
-                         rows.data(), nrows, &nrows));
+namespace {
+// TSV text of the rows of ONE ctg (sw.rs:152-190), `rows` in the device's order (feature, then M, L1.., R1..)
+std::string sw_format_rows(const gams_sw_row_t *rows, uint64_t nrows, const Ctg &ctg, const std::vector<Feature> &features,
+                           unsigned max_threads) {
     static const char *TYPES[3] = {"M", "L", "R"};
     // text of rows [r0, r1), r0 on a feature boundary (the serial number restarts per feature)
     auto format = [&](uint64_t r0, uint64_t r1, std::string &o) {
@@ -678,8 +673,9 @@ std::string sw_proc_ctg(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq, const
             o += "\t\n";                                                // empty rg_count (data.rs:71-80)
         }
     };
+    std::string out;
     // a few host threads, each a run of whole features
-    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({8, std::thread::hardware_concurrency(), nrows / 20000}));
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({max_threads, std::thread::hardware_concurrency(), nrows / 20000}));
     if (T <= 1) {
         format(0, nrows, out);
         return out;
@@ -700,6 +696,112 @@ std::string sw_proc_ctg(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq, const
     for (auto &x : part) total += x.size();
     out.reserve(total);
     for (auto &x : part) out += x;
+    return out;
+}
+}  // namespace
+
+std::string sw_proc_ctg(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq, const std::vector<Feature> &features,
+                        const SwArgs &a) {
+    const uint32_t nf = (uint32_t)features.size();
+    if (nf == 0) return std::string();
+    uint32_t len = (uint32_t)(ctg.chr_end - ctg.chr_start + 1);
+    SeqSetGuard sg{h};
+    check(h, gams_seqset_create(h, 1, &len, &sg.s));
+    check(h, gams_seqset_upload(h, sg.s, 0, seq));
+    std::vector<int32_t> fs(nf), fe(nf);
+    for (uint32_t f = 0; f < nf; ++f) {
+        fs[f] = features[f].start;
+        fe[f] = features[f].end;
+    }
+    uint64_t nrows = 0;
+    check(h, gams_gpu_sw(h, sg.s, 0, ctg.chr_start, fs.data(), fe.data(), nf, a.size, a.max, a.resize, nullptr, 0,
+                         &nrows));
+    std::vector<gams_sw_row_t> rows(nrows ? nrows : 1);
+    check(h, gams_gpu_sw(h, sg.s, 0, ctg.chr_start, fs.data(), fe.data(), nf, a.size, a.max, a.resize,
+                         rows.data(), nrows, &nrows));
+    return sw_format_rows(rows.data(), nrows, ctg, features, 8);
+}
+
+// Several ctgs on one handle: their sequences go into one seqset per batch of <= batch_bytes bases, all
+// features of a batch through ONE gams_gpu_sw_batch call (one upload, one gc index, one launch, one readback
+// into page-locked memory), and the rows of the batch's ctgs are formatted on host threads, a ctg each.
+std::vector<std::string> sw_proc_ctgs(gams_gpu_t *h, const std::vector<Ctg> &ctgs, const std::vector<const uint8_t *> &seqs,
+                                      const std::vector<std::vector<Feature>> &features, const SwArgs &a,
+                                      uint64_t batch_bytes) {
+    if (ctgs.size() != seqs.size() || ctgs.size() != features.size())
+        throw Error(GAMS_EINVAL, "sw_proc_ctgs: ctgs / seqs / features size mismatch");
+    std::vector<std::string> out(ctgs.size());
+    std::vector<size_t> todo;                                           // ctgs with features, in ctg order
+    for (size_t c = 0; c < ctgs.size(); ++c)
+        if (!features[c].empty()) todo.push_back(c);
+    for (size_t b = 0; b < todo.size();) {
+        uint64_t bytes = 0;
+        size_t e = b;
+        while (e < todo.size()) {
+            const uint64_t len = (uint64_t)(ctgs[todo[e]].chr_end - ctgs[todo[e]].chr_start + 1);
+            if (e > b && bytes + len > batch_bytes) break;
+            bytes += len;
+            ++e;
+        }
+        const uint32_t n = (uint32_t)(e - b);
+        std::vector<uint32_t> lens(n), index(n);
+        std::vector<const uint8_t *> ptrs(n);
+        std::vector<int32_t> chr_start(n);
+        std::vector<uint64_t> feat_off(n + 1, 0);
+        for (uint32_t k = 0; k < n; ++k) {
+            const Ctg &c = ctgs[todo[b + k]];
+            lens[k] = (uint32_t)(c.chr_end - c.chr_start + 1);
+            ptrs[k] = seqs[todo[b + k]];
+            index[k] = k;
+            chr_start[k] = c.chr_start;
+            feat_off[k + 1] = feat_off[k] + features[todo[b + k]].size();
+        }
+        std::vector<int32_t> fs(feat_off[n]), fe(feat_off[n]);
+        for (uint32_t k = 0; k < n; ++k) {
+            const std::vector<Feature> &fv = features[todo[b + k]];
+            for (size_t f = 0; f < fv.size(); ++f) {
+                fs[feat_off[k] + f] = fv[f].start;
+                fe[feat_off[k] + f] = fv[f].end;
+            }
+        }
+        SeqSetGuard sg{h};
+        check(h, gams_seqset_create(h, n, lens.data(), &sg.s));
+        check(h, gams_seqset_upload_all(h, sg.s, ptrs.data()));
+        std::vector<uint64_t> row_off(n + 1, 0);
+        uint64_t nrows = 0;
+        check(h, gams_gpu_sw_batch(h, sg.s, n, index.data(), chr_start.data(), feat_off.data(), fs.data(), fe.data(),
+                                   a.size, a.max, a.resize, nullptr, 0, row_off.data(), &nrows));
+        // rows land in page-locked memory: the readback runs at the rate of the link
+        struct Pinned {
+            gams_gpu_t *h;
+            void *p = nullptr;
+            ~Pinned() { if (p) gams_gpu_host_free(h, p); }
+        } pin{h};
+        check(h, gams_gpu_host_alloc(h, std::max<uint64_t>(nrows, 1) * sizeof(gams_sw_row_t), &pin.p));
+        gams_sw_row_t *rows = static_cast<gams_sw_row_t *>(pin.p);
+        check(h, gams_gpu_sw_batch(h, sg.s, n, index.data(), chr_start.data(), feat_off.data(), fs.data(), fe.data(),
+                                   a.size, a.max, a.resize, rows, nrows, row_off.data(), &nrows));
+        // format: ctgs of the batch dealt to a few host threads
+        const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({16, std::thread::hardware_concurrency(), (uint64_t)n}));
+        std::atomic<uint32_t> next{0};
+        std::vector<std::exception_ptr> errs(T);
+        auto work = [&](unsigned t) {
+            try {
+                for (uint32_t k = next.fetch_add(1); k < n; k = next.fetch_add(1))
+                    out[todo[b + k]] = sw_format_rows(rows + row_off[k], row_off[k + 1] - row_off[k], ctgs[todo[b + k]],
+                                                      features[todo[b + k]], T > 1 ? 1 : 8);
+            } catch (...) {
+                errs[t] = std::current_exception();
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < T; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto &th : pool) th.join();
+        for (auto &er : errs)
+            if (er) std::rethrow_exception(er);
+        b = e;
+    }
     return out;
 }
 

@@ -102,6 +102,11 @@ void cover_multi(const std::vector<gams_gpu_t *> &handles, uint32_t n_groups, co
 // sw.rs:108-194
 std::string sw_proc_ctg(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq, const std::vector<Feature> &features,
                         const SwArgs &a);
+// several ctgs on one handle: one seqset, one gams_gpu_sw_batch call and one readback per batch of
+// <= batch_bytes bases; rows returned per ctg in the order given ("" for a ctg without features)
+std::vector<std::string> sw_proc_ctgs(gams_gpu_t *h, const std::vector<Ctg> &ctgs, const std::vector<const uint8_t *> &seqs,
+                                      const std::vector<std::vector<Feature>> &features, const SwArgs &a,
+                                      uint64_t batch_bytes = 256ull << 20);
 // `gams sw --parallel` over several devices: ctgs split over the handles by LPT on their feature
 // counts, one host thread per handle, rows returned per ctg in the order given.
 std::vector<std::string> sw_proc_ctgs_multi(const std::vector<gams_gpu_t *> &handles, const std::vector<Ctg> &ctgs,

@@ -14,7 +14,7 @@
  * Reference interfaces replaced (paths under wang-q/gams @ 2024-10-22):
  *   gams_gpu_wave*            src/cmd_gams/wave.rs:138-155  (sliding + gc_content + thresholding_algo)
  *                             = src/libs/window.rs:78-94, bio gc_content, src/libs/stat.rs:16-56
- *   gams_gpu_sw               src/cmd_gams/sw.rs:141-184    (center_sw + cache_gc_content + cache_gc_stat)
+ *   gams_gpu_sw(_batch)       src/cmd_gams/sw.rs:141-184    (center_sw + cache_gc_content + cache_gc_stat)
  *                             = src/libs/window.rs:3-56,96-124, src/libs/utils.rs:141-213
  *   gams_gpu_count            src/libs/utils.rs:24-36       (count_rg -> Lapper::count)
  *   gams_gpu_locate           src/libs/utils.rs:7-22        (find_one_idx -> Lapper::find().next())
@@ -211,6 +211,18 @@ int gams_gpu_sw(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, int32_t chr_start,
                 const int32_t *feat_start, const int32_t *feat_end, uint32_t nf,
                 int32_t size, int32_t max, int32_t resize, gams_sw_row_t *rows,
                 uint64_t cap, uint64_t *n_rows);
+
+/* The same over several ctgs of the seqset in ONE launch and one pair of transfers (a ctg's few hundred
+ * features are a handful of workgroups: called per ctg the kernel is all launch latency).  ctg_index[k]
+ * (k < n_sel) names a ctg of `s`, chr_start[k] its first chromosome coordinate; its features are
+ * feat_start / feat_end [feat_off[k], feat_off[k+1]) (feat_off[0] = 0).  Rows come out in (k, feature, M,
+ * L1.., R1..) order, `feature` counting from 0 inside each selected ctg; row_off (n_sel + 1 entries, may be
+ * NULL) receives where the rows of selected ctg k begin.  rows == NULL or cap == 0: size query (n_rows and
+ * row_off only, nothing runs on the device).  gams_gpu_sw is this call with n_sel = 1. */
+int gams_gpu_sw_batch(gams_gpu_t *h, gams_seqset_t *s, uint32_t n_sel, const uint32_t *ctg_index,
+                      const int32_t *chr_start, const uint64_t *feat_off, const int32_t *feat_start,
+                      const int32_t *feat_end, int32_t size, int32_t max, int32_t resize,
+                      gams_sw_row_t *rows, uint64_t cap, uint64_t *row_off, uint64_t *n_rows);
 
 /* gc_content (round4, utils.rs:141-162) of n chromosome ranges inside ctg i: what `gams peak`
  * asks per merged peak (peak.rs:79; second "next" row of SURVEY section 8f). */

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import helpers
-from gams_amd import engine, host
+from gams_amd import _lib, engine, host
 from oracle import oracle as ora
 
 pytestmark = pytest.mark.gpu
@@ -398,6 +398,59 @@ def test_sw_multi_handles_equals_per_ctg(eng, s288c, n_handles):
     for x in engs[1:]:
         x.close()
     assert got == exp
+
+
+def test_sw_batch_call_equals_one_call_per_ctg(eng, s288c):
+    """gams_gpu_sw_batch (every selected ctg in one launch) against gams_gpu_sw per ctg: same rows in (ctg,
+    feature, M/L/R) order, `feature` counted inside each ctg, row_off = where each ctg's rows begin; a
+    selection that skips, repeats and reorders ctgs; the size query runs nothing on the device."""
+    import ctypes as C
+    ctgs = helpers.gen_ctgs("I", s288c["I"], piece=30000)[:7]
+    rng = np.random.default_rng(11)
+    ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])
+    feats = []
+    for c in ctgs:
+        n = int(rng.integers(0, 60))
+        a = rng.integers(c["chr_start"], c["chr_end"] + 1, n).astype(np.int32)
+        b = np.minimum(a + rng.choice([0, 1, 50, 999], n), c["chr_end"]).astype(np.int32)
+        feats.append((a, b))
+    lib = eng.lib
+
+    def per_ctg(i):
+        a, b = feats[i]
+        n = C.c_uint64()
+        rows = np.zeros(max(a.size * 41, 1), _lib.SW_ROW_DTYPE)
+        eng.check(lib.gams_gpu_sw(eng.h, ss.p, i, ctgs[i]["chr_start"], a.ctypes.data, b.ctypes.data, a.size, 100, 20, 500,
+                                  rows.ctypes.data, rows.size, C.byref(n)))
+        return rows[:n.value]
+
+    for sel in ([0, 1, 2, 3, 4, 5, 6], [5, 2, 2, 6], [3]):
+        sel_a = np.array(sel, np.uint32)
+        cst = np.array([ctgs[i]["chr_start"] for i in sel], np.int32)
+        foff = np.concatenate([[0], np.cumsum([feats[i][0].size for i in sel])]).astype(np.uint64)
+        fs = np.ascontiguousarray(np.concatenate([feats[i][0] for i in sel]), np.int32)
+        fe = np.ascontiguousarray(np.concatenate([feats[i][1] for i in sel]), np.int32)
+        n = C.c_uint64()
+        roff = np.zeros(len(sel) + 1, np.uint64)
+        args = (eng.h, ss.p, len(sel), sel_a.ctypes.data, cst.ctypes.data, foff.ctypes.data, fs.ctypes.data, fe.ctypes.data,
+                100, 20, 500)
+        eng.check(lib.gams_gpu_sw_batch(*args, None, 0, roff.ctypes.data, C.byref(n)))          # size query
+        exp = [per_ctg(i) for i in sel]
+        assert n.value == sum(e.size for e in exp)
+        assert np.array_equal(roff, np.concatenate([[0], np.cumsum([e.size for e in exp])]).astype(np.uint64))
+        rows = np.zeros(max(n.value, 1), _lib.SW_ROW_DTYPE)
+        roff2 = np.zeros_like(roff)
+        eng.check(lib.gams_gpu_sw_batch(*args, rows.ctypes.data, rows.size, roff2.ctypes.data, C.byref(n)))
+        assert np.array_equal(roff2, roff)
+        got = rows[:n.value]
+        assert got.tobytes() == (np.concatenate(exp).tobytes() if n.value else b""), sel
+    # bad selections
+    one = np.array([99], np.uint32)
+    z = np.zeros(2, np.uint64)
+    n = C.c_uint64()
+    assert lib.gams_gpu_sw_batch(eng.h, ss.p, 1, one.ctypes.data, cst.ctypes.data, z.ctypes.data, None, None, 100, 20, 500,
+                                 None, 0, None, C.byref(n)) == _lib.EINVAL
+    ss.close()
 
 
 def test_sw_rejects_features_whose_middle_is_outside_the_ctg(eng, s288c):

@@ -28,21 +28,34 @@ rng = np.random.default_rng(5)
 chrom = synth.chromosome(30_000_000, 9)
 ctgs = synth.gen_ctgs("9", chrom, piece=1000000)
 ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])
-rows_total, ms_total = 0, 0.0
-for rep in range(2):
+nf = 100000 // len(ctgs)
+feats = [np.sort(rng.integers(c["chr_start"], c["chr_end"] + 1, nf)).astype(np.int32) for c in ctgs]
+for rep in range(2):                                   # one launch per ctg (gams_gpu_sw)
     rows_total, ms_total = 0, 0.0
     for i, c in enumerate(ctgs):
-        nf = 100000 // len(ctgs)
-        fs = np.sort(rng.integers(c["chr_start"], c["chr_end"] + 1, nf)).astype(np.int32)
-        fe = fs.copy()
         n = C.c_uint64()
         rows = np.zeros(nf * 41, _lib.SW_ROW_DTYPE)
-        eng.check(lib.gams_gpu_sw(eng.h, ss.p, i, c["chr_start"], fs.ctypes.data, fe.ctypes.data, nf, 100, 20, 500,
-                                  rows.ctypes.data, rows.size, C.byref(n)))
+        eng.check(lib.gams_gpu_sw(eng.h, ss.p, i, c["chr_start"], feats[i].ctypes.data, feats[i].ctypes.data, nf, 100, 20,
+                                  500, rows.ctypes.data, rows.size, C.byref(n)))
         rows_total += n.value
         ms_total += kernel_ms()
-print(f"sw: {rows_total} rows in {ms_total:.3f} ms kernel time -> {rows_total / ms_total / 1e6:.2f} G rows/s, "
-      f"{rows_total * 84 / ms_total / 1e6:.1f} GB/s at 84 B/row")
+print(f"sw, one call per ctg ({len(ctgs)} launches): {rows_total} rows in {ms_total:.3f} ms kernel time -> "
+      f"{rows_total / ms_total / 1e6:.2f} G rows/s, {rows_total * 84 / ms_total / 1e6:.1f} GB/s at 84 B/row")
+sel = np.arange(len(ctgs), dtype=np.uint32)            # every ctg in one launch (gams_gpu_sw_batch)
+cst = np.array([c["chr_start"] for c in ctgs], np.int32)
+foff = (np.arange(len(ctgs) + 1) * nf).astype(np.uint64)
+fall = np.ascontiguousarray(np.concatenate(feats), np.int32)
+n = C.c_uint64()
+rows = np.zeros(nf * 41 * len(ctgs), _lib.SW_ROW_DTYPE)
+for rep in range(3):
+    t0 = time.time()
+    eng.check(lib.gams_gpu_sw_batch(eng.h, ss.p, sel.size, sel.ctypes.data, cst.ctypes.data, foff.ctypes.data,
+                                    fall.ctypes.data, fall.ctypes.data, 100, 20, 500, rows.ctypes.data, rows.size, None,
+                                    C.byref(n)))
+    call_s = time.time() - t0
+ms = kernel_ms()
+print(f"sw, one batched call: {n.value} rows in {ms:.3f} ms kernel time -> {n.value / ms / 1e6:.2f} G rows/s, "
+      f"{n.value * 84 / ms / 1e6:.1f} GB/s at 84 B/row; whole call (rows to pageable host memory) {call_s * 1e3:.1f} ms")
 
 # ---- locate --count: 1.25e7 stored points + 1.25e7 queries over 4000 ctgs (config 4 per-GPU share) ----
 n_ctg, per = 4000, 1_000_000

@@ -30,3 +30,14 @@ for rep in range(3):
     dt = time.perf_counter() - t0
     print(f"sw end to end: {rows} rows ({nbytes / 1e6:.0f} MB of text) for {sum(len(v) for v in feats.values())} features "
           f"on {len(ctgs)} ctgs in {dt * 1e3:.0f} ms -> {rows / dt / 1e6:.2f} M rows/s", flush=True)
+
+# the same through the batched host path (sw_proc_ctgs: one seqset, one gams_gpu_sw_batch call, rows read back into
+# page-locked memory, ctgs formatted on host threads)
+flist = [feats[c["id"]] for c in ctgs]
+for rep in range(3):
+    t0 = time.perf_counter()
+    out = host.sw_multi([eng], ctgs, flist)
+    dt = time.perf_counter() - t0
+    rows = out.count("\n")
+    print(f"sw end to end, batched: {rows} rows ({len(out) / 1e6:.0f} MB of text) in {dt * 1e3:.0f} ms -> "
+          f"{rows / dt / 1e6:.2f} M rows/s", flush=True)
