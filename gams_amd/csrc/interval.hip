@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void interval_locate_kernel(const IndexGroup *
 
 // covered positions <= x inside the group's spans
 __device__ __forceinline__ uint64_t covered_upto(const SpanRec *rec, const uint32_t *dir, const SpanGroup &G,
-                                                 uint32_t g, int32_t x) {
+                                                 uint32_t g, int32_t x, uint32_t *rank) {
     // spans with lo <= x = keys < x+1 in biased order; directory lookup, then a search over rec[].lo
     const SpanRec *r = rec + G.off;
     uint32_t i = 0;
@@ -232,10 +232,31 @@ __device__ __forceinline__ uint64_t covered_upto(const SpanRec *rec, const uint3
             i = lo;
         }
     }
+    if (rank) *rank = i;
     if (i == 0) return 0;
     const SpanRec s = r[i - 1];
     const int32_t top = s.hi < x ? s.hi : x;
     return s.cum + (uint64_t)((int64_t)top - s.lo + 1);
+}
+
+// The same for a second position x2 <= x whose predecessor `rank` (spans with lo <= x) is known: a range is
+// short next to the spans' spacing, so the spans with lo <= x2 end zero to two records further down -- a walk
+// over neighbouring 16-B records instead of a second directory line + search (two scattered requests less per
+// line).  A long walk gives up and searches.
+__device__ __forceinline__ uint64_t covered_upto_below(const SpanRec *rec, const uint32_t *dir, const SpanGroup &G,
+                                                       uint32_t g, int32_t x2, uint32_t rank) {
+    const SpanRec *r = rec + G.off;
+    uint32_t i = rank;
+    for (int step = 0; step < 6; ++step) {
+        if (i == 0) return 0;
+        const SpanRec s = r[i - 1];
+        if (s.lo <= x2) {
+            const int32_t top = s.hi < x2 ? s.hi : x2;
+            return s.cum + (uint64_t)((int64_t)top - s.lo + 1);
+        }
+        --i;
+    }
+    return covered_upto(rec, dir, G, g, x2, nullptr);
 }
 
 __global__ __launch_bounds__(256) void span_cover_kernel(const SpanGroup *groups, const SpanRec *rec,
@@ -254,8 +275,9 @@ __global__ __launch_bounds__(256) void span_cover_kernel(const SpanGroup *groups
         uint64_t card = 0;
         if (H >= L) {
             const SpanGroup G = groups[g];
-            const uint64_t upto_h = covered_upto(rec, dir, G, g, H);
-            const uint64_t upto_l = L > INT32_MIN ? covered_upto(rec, dir, G, g, L - 1) : 0;
+            uint32_t rank_h;
+            const uint64_t upto_h = covered_upto(rec, dir, G, g, H, &rank_h);
+            const uint64_t upto_l = L > INT32_MIN ? covered_upto_below(rec, dir, G, g, L - 1, rank_h) : 0;
             card = upto_h - upto_l;
         }
         const int32_t total = (int32_t)((int64_t)e - s + 1);
