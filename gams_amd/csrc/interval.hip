@@ -74,6 +74,10 @@ struct BkRec {
     uint32_t rank;
     uint32_t k[7];
 };
+#ifndef GAMS_CELL_SHIFT
+#define GAMS_CELL_SHIFT 1
+#endif
+constexpr uint32_t kCellShift = GAMS_CELL_SHIFT;   // about 2^kCellShift keys per cell of the count path's grid
 
 struct SpanRec {
     int32_t lo, hi;   // inclusive
@@ -95,8 +99,8 @@ struct gams_index {
     uint32_t *d_lstart = nullptr;    // per group, starts of the (start,stop)-sorted pairs: ascending (both searches)
     IvRec *d_lrec = nullptr;         // the sorted pairs + the caller's index of each, 16 B (locate's scan)
     uint32_t *d_dir_start = nullptr; // m + n_groups entries: group g's directory begins at off[g] + g (locate)
-    BkRec *d_bk_start = nullptr;     // m/4 + 2*n_groups + 2 records: group g's begin at off[g]/4 + 2g
-    BkRec *d_bk_stop = nullptr;
+    BkRec *d_bk_start = nullptr;     // 2 * (m/4 + 2*n_groups + 2) records, the starts' and the stops' record of a cell side by side;
+    BkRec *d_bk_stop = nullptr;      // = d_bk_start + 1; group g's cells begin at off[g]/4 + 2g
     CountGroup *d_cgroups = nullptr;
     // everything above lives in one pooled HBM block
     uint8_t *arena = nullptr;
@@ -138,7 +142,7 @@ __device__ __forceinline__ uint32_t bk_lower_bound(const uint32_t *keys, const B
     if (n == 0 || key <= (uint64_t)d.key0) return 0;
     const uint64_t b = (key - d.key0) >> d.shift;
     if (b >= d.nb) return n;
-    const uint4 *rp = reinterpret_cast<const uint4 *>(bk + b);
+    const uint4 *rp = reinterpret_cast<const uint4 *>(bk + 2u * b);   // the cell's pair of records: starts', stops'
     const uint4 r0 = rp[0], r1 = rp[1];
     const uint32_t rank = r0.x;
     uint32_t c = (uint32_t)((uint64_t)r0.y < key) + (uint32_t)((uint64_t)r0.z < key) + (uint32_t)((uint64_t)r0.w < key) +
@@ -146,7 +150,23 @@ __device__ __forceinline__ uint32_t bk_lower_bound(const uint32_t *keys, const B
                  (uint32_t)((uint64_t)r1.w < key);
     c = min(c, n - rank);                            // padding past the group's end does not count
     if (c < 7u || rank + 7u >= n) return rank + c;
-    uint32_t lo = rank + 7u, hi = n;                 // a crowded bucket: go on in the key array
+    // A crowded cell (more than seven keys; 5 % of uniform cells, i.e. some lane of nearly every wave): the
+    // answer lies between rank + 7 and the next cell's rank.  One load for that rank (the neighbouring
+    // record), then the next eight keys in one batch of independent loads -- two round trips instead of the
+    // ~12 dependent ones of a binary search over the group, which made every wave of random queries live 26 us
+    // (33 dependent loads, profiles/r02_count_latency_chain.txt).  A cell of more than 15 keys goes on with
+    // the binary search, inside the cell.
+    uint32_t lo = rank + 7u;
+    uint32_t hi = b + 1u < d.nb ? reinterpret_cast<const uint32_t *>(bk + 2u * (b + 1u))[0] : n;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 8u; ++i) {
+        const uint32_t k = keys[min(lo + i, n - 1u)];
+        cnt += (lo + i < hi && (uint64_t)k < key) ? 1u : 0u;
+    }
+    if (hi - lo <= 8u) return lo + cnt;
+    if (cnt < 8u) return lo + cnt;                   // sorted keys: the first one >= key ends the count
+    lo += 8u;
     while (lo < hi) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
         if ((uint64_t)keys[mid] < key)
@@ -173,10 +193,12 @@ __global__ __launch_bounds__(256) void interval_count_kernel(const CountGroup *g
     const uint4 g0 = gp[0], g1 = gp[1];
     const uint32_t off = g0.x, n = g0.y;
     const KeyDir ds{g0.z, g1.z, g0.w, 0u}, dt{g1.x, g1.w, g1.y, 0u};
-    const uint64_t boff = (uint64_t)(off >> 2) + 2ull * g;
+    const uint64_t boff = (uint64_t)(off >> kCellShift) + 2ull * g;
     // Lapper::count: first = bsearch_seq(start + 1, stops); last = bsearch_seq(stop, starts)
-    const uint32_t first = bk_lower_bound(stops + off, bk_stop + boff, n, dt, (uint64_t)qs[q] + 1u);
-    const uint32_t last = bk_lower_bound(starts + off, bk_start + boff, n, ds, (uint64_t)qe[q]);
+    // (bk_start = the interleaved array, bk_stop = bk_start + 1: a range shorter than a cell finds both of its
+    // records in one 64-B line or in two neighbouring ones)
+    const uint32_t first = bk_lower_bound(stops + off, bk_stop + 2u * boff, n, dt, (uint64_t)qs[q] + 1u);
+    const uint32_t last = bk_lower_bound(starts + off, bk_start + 2u * boff, n, ds, (uint64_t)qe[q]);
     out[q] = (int32_t)((int64_t)last - (int64_t)first);
 }
 
@@ -338,8 +360,11 @@ __global__ __launch_bounds__(64) void index_group_kernel(const uint32_t *off32, 
         G.maxlen = ml;
         G.start = n ? dir_params(lstart[lo], lstart[hi - 1], n) : KeyDir{0u, 0u, 0u, 0u};
         G.stop = n ? dir_params(stops_sorted[lo], stops_sorted[hi - 1], n) : KeyDir{0u, 0u, 0u, 0u};
-        G.bk_start = n ? dir_params(lstart[lo], lstart[hi - 1], n / 4u + 1u) : KeyDir{0u, 0u, 0u, 0u};
-        G.bk_stop = n ? dir_params(stops_sorted[lo], stops_sorted[hi - 1], n / 4u + 1u) : KeyDir{0u, 0u, 0u, 0u};
+        // the count path's bucket records: ONE grid of cells over the group's coordinates for both key
+        // arrays, so that the record of the starts and the record of the stops of a cell sit side by side
+        G.bk_start = n ? dir_params(min(lstart[lo], stops_sorted[lo]), max(lstart[hi - 1], stops_sorted[hi - 1]), (n >> kCellShift) + 1u)
+                       : KeyDir{0u, 0u, 0u, 0u};
+        G.bk_stop = G.bk_start;
         groups[g] = G;
         cgroups[g] = CountGroup{lo, n, G.bk_start.key0, G.bk_start.nb, G.bk_stop.key0, G.bk_stop.nb, G.bk_start.shift,
                                 G.bk_stop.shift};
@@ -393,14 +418,14 @@ __global__ __launch_bounds__(256) void index_bk_kernel(const uint32_t *off32, ui
     uint32_t lo = 0, hi = n_groups;
     while (hi - lo > 1u) {
         const uint32_t mid = (lo + hi) >> 1;
-        if ((uint64_t)(off32[mid] >> 2) + 2ull * mid <= j)
+        if ((uint64_t)(off32[mid] >> kCellShift) + 2ull * mid <= j)
             lo = mid;
         else
             hi = mid;
     }
     const uint32_t g = lo;
     const IndexGroup G = groups[g];
-    const uint64_t b = j - ((uint64_t)(off32[g] >> 2) + 2ull * g);
+    const uint64_t b = j - ((uint64_t)(off32[g] >> kCellShift) + 2ull * g);
     auto fill = [&](const uint32_t *keys, const KeyDir d, BkRec *bk) {
         if (G.n == 0 || b >= d.nb) return;
         const uint64_t edge = (uint64_t)d.key0 + (b << d.shift);
@@ -416,7 +441,7 @@ __global__ __launch_bounds__(256) void index_bk_kernel(const uint32_t *off32, ui
         r.rank = a;
 #pragma unroll
         for (uint32_t i = 0; i < 7u; ++i) r.k[i] = a + i < G.n ? keys[G.off + a + i] : 0xffffffffu;
-        bk[j] = r;
+        bk[2u * j] = r;                                // cell j: starts' record, stops' record (64 B together)
     };
     fill(lstart, G.bk_start, bk_start);
     fill(stops_sorted, G.bk_stop, bk_stop);
@@ -576,7 +601,7 @@ int gams_index_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
     const size_t b_cg = al((size_t)ng1 * sizeof(CountGroup));
     const size_t b_groups = al((size_t)ng1 * sizeof(IndexGroup)), b_u32 = al(std::max<uint64_t>(m, 1) * 4),
                  b_rec = al(std::max<uint64_t>(m, 1) * sizeof(IvRec)), b_dir = al((m + n_groups + 1) * 4);
-    const uint64_t bk_slots = m / 4 + 2ull * n_groups + 2;
+    const uint64_t bk_slots = (m >> kCellShift) + 2ull * n_groups + 2;
     const size_t b_bk = al(bk_slots * sizeof(BkRec));
     gams_index_t *ix = new gams_index_t();
     ix->n_groups = n_groups;
@@ -613,9 +638,8 @@ int gams_index_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
         p += b_rec;
         ix->d_dir_start = reinterpret_cast<uint32_t *>(p);
         p += b_dir;
-        ix->d_bk_start = reinterpret_cast<BkRec *>(p);
-        p += b_bk;
-        ix->d_bk_stop = reinterpret_cast<BkRec *>(p);
+        ix->d_bk_start = reinterpret_cast<BkRec *>(p);     // 2 * bk_slots records, interleaved: cell j = [2j] starts, [2j+1] stops
+        ix->d_bk_stop = ix->d_bk_start + 1;
     }
     e = gams_pool_alloc(h, false, 2 * b_u32 + 2 * b_key + 2 * b_u32 + b_off, reinterpret_cast<void **>(&scratch),
                         &scratch_bytes);

@@ -12,7 +12,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gams_amd import _lib, engine, synth  # noqa: E402
 
-eng = engine.Engine(0)
+# optional argument: another build of libgams_gpu.so to measure (A/B of index layouts)
+eng = engine.Engine(0, lib=_lib.bind(os.path.abspath(sys.argv[1]), strict=False)) if len(sys.argv) > 1 else engine.Engine(0)
 lib = eng.lib
 
 

@@ -30,6 +30,6 @@ for n_ctg in (250, 500, 1000, 2000, 4000, 8000):
         eng.check(lib.gams_gpu_count(eng.h, ix, qg.ctypes.data, qs.ctypes.data, qe.ctypes.data, nq, out.ctypes.data))
     ms = C.c_float()
     eng.check(lib.gams_gpu_last_kernel_ms(eng.h, C.byref(ms)))
-    print(f"{m:9d} intervals in {n_ctg:5d} ctgs ({m * 16 / 1e6:6.0f} MB of bucket records): {nq / ms.value / 1e6:6.2f} G queries/s "
+    print(f"{m:9d} intervals in {n_ctg:5d} ctgs ({m * 32 / 1e6:6.0f} MB of bucket records): {nq / ms.value / 1e6:6.2f} G queries/s "
           f"({ms.value:.3f} ms)")
     lib.gams_index_destroy(eng.h, ix)
