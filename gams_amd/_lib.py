@@ -78,6 +78,7 @@ PROTOTYPES = {
     "gams_gpu_sw_batch": (C.c_int, [_VP, _VP, C.c_uint32, _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32, C.c_int32,
                                     _VP, C.c_uint64, _VP, _VP]),
     "gams_gpu_range_gc": (C.c_int, [_VP, _VP, C.c_uint32, C.c_int32, _VP, _VP, C.c_uint32, _VP]),
+    "gams_gpu_range_gc_batch": (C.c_int, [_VP, _VP, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP]),
     "gams_index_create": (C.c_int, [_VP, C.c_uint32, _VP, _VP, _VP, _PP]),
     "gams_index_destroy": (None, [_VP, _VP]),
     "gams_gpu_count": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_uint64, _VP]),

@@ -297,11 +297,18 @@ __global__ __launch_bounds__(256) void sw_kernel(const SwArgs a0) {
     a.rows[row] = r;
 }
 
-// peak (src/cmd_gams/peak.rs:79) / any caller of cache_gc_content: one lane per range
-__global__ __launch_bounds__(256) void range_gc_kernel(const SwArgs a, const int32_t *rs, const int32_t *re,
+// peak (src/cmd_gams/peak.rs:79) / any caller of cache_gc_content: one lane per range, the ranges of every
+// selected ctg in one launch (a.ctgs / a.fctg as in sw_kernel)
+__global__ __launch_bounds__(256) void range_gc_kernel(const SwArgs a0, const int32_t *rs, const int32_t *re,
                                                        uint32_t n, float *gc) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
+    const SwCtg cg = a0.ctgs[a0.fctg[q]];
+    SwArgs a = a0;
+    a.seq_off = cg.seq_off;
+    a.len = cg.len;
+    a.chr_start = cg.chr_start;
+    a.chr_end = cg.chr_end;
     gc[q] = round4(range_gc(a, rs[q], re[q]));                          // utils.rs:157-161
 }
 
@@ -502,59 +509,103 @@ extern "C" int gams_gpu_sw(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, int32_t 
 
 // gc_content (round4) of arbitrary chromosome ranges inside ctg i: gams::cache_gc_content
 // (src/libs/utils.rs:141-162) as `gams peak` uses it (src/cmd_gams/peak.rs:79).
-extern "C" int gams_gpu_range_gc(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, int32_t chr_start,
-                                 const int32_t *range_start, const int32_t *range_end, uint32_t n, float *gc) {
-    if (!h || !s || (n && (!range_start || !range_end || !gc)))
+extern "C" int gams_gpu_range_gc_batch(gams_gpu_t *h, gams_seqset_t *s, uint32_t n_sel, const uint32_t *ctg_index,
+                                       const int32_t *chr_start, const uint64_t *range_off, const int32_t *range_start,
+                                       const int32_t *range_end, float *gc) {
+    if (!h || !s || (n_sel && (!ctg_index || !chr_start || !range_off)))
         return gams_fail(h, GAMS_EINVAL, "gpu_range_gc: null argument");
-    if (i >= s->n_ctg) return gams_fail(h, GAMS_EINVAL, "gpu_range_gc: ctg index out of range");
-    if (s->len[i] == 0 || s->len[i] > 0x7fffffffu) return gams_fail(h, GAMS_EINVAL, "gpu_range_gc: ctg length out of range");
-    {
-        // utils.rs:151-156 slices seq[from-1..to): a range outside the ctg (or inverted) panics there
-        const int64_t chr_end = (int64_t)chr_start + s->len[i] - 1;
-        for (uint32_t k = 0; k < n; ++k)
-            if (range_start[k] < chr_start || range_end[k] > chr_end || range_end[k] < range_start[k])
-                return gams_fail(h, GAMS_EINVAL, "gpu_range_gc: range " + std::to_string(k) + " is not inside the ctg");
+    if (n_sel == 0) return GAMS_OK;
+    if (range_off[0] != 0) return gams_fail(h, GAMS_EINVAL, "gpu_range_gc: range_off[0] must be 0");
+    for (uint32_t k = 0; k < n_sel; ++k) {
+        if (ctg_index[k] >= s->n_ctg) return gams_fail(h, GAMS_EINVAL, "gpu_range_gc: ctg index out of range");
+        if (range_off[k + 1] < range_off[k]) return gams_fail(h, GAMS_EINVAL, "gpu_range_gc: range_off must not decrease");
+        const uint32_t len = s->len[ctg_index[k]];
+        if (len == 0 || len > 0x7fffffffu) return gams_fail(h, GAMS_EINVAL, "gpu_range_gc: ctg length out of range");
     }
+    const uint64_t n64 = range_off[n_sel];
+    if (n64 == 0) return GAMS_OK;
+    if (!range_start || !range_end || !gc) return gams_fail(h, GAMS_EINVAL, "gpu_range_gc: null argument");
+    if (n64 > 0x7fffff00ull) return gams_fail(h, GAMS_EUNSUPPORTED, "gpu_range_gc: too many ranges for one launch");
+    const uint32_t n = (uint32_t)n64;
     GAMS_HIP(h, hipSetDevice(h->device));
-    if (n == 0) return GAMS_OK;
-    int rc = gams_seqset_gcindex(h, s);
-    if (rc != GAMS_OK) return rc;
-    int32_t *d_rs = nullptr, *d_re = nullptr;
-    float *d_gc = nullptr;
-    auto cleanup = [&]() {
-        (void)hipFree(d_rs);
-        (void)hipFree(d_re);
-        (void)hipFree(d_gc);
+    // inputs in one page-locked block (one DMA): ctgs | rs | re | rctg; results in the same device block
+    const size_t b_ctg = ((size_t)n_sel * sizeof(SwCtg) + 255) & ~(size_t)255;
+    const size_t b_i32 = ((size_t)n * sizeof(int32_t) + 255) & ~(size_t)255;
+    const size_t in_bytes = b_ctg + 3 * b_i32;
+    uint8_t *pin = nullptr, *dev = nullptr;
+    size_t pin_cap = 0, dev_cap = 0;
+    hipError_t e = gams_pool_alloc(h, true, in_bytes, reinterpret_cast<void **>(&pin), &pin_cap);
+    if (e != hipSuccess) return gams_fail(h, GAMS_ENOMEM, std::string("gpu_range_gc: pinned staging: ") + hipGetErrorString(e));
+    auto release = [&]() {
+        if (pin) gams_pool_free(h, true, pin, pin_cap);
+        if (dev) gams_pool_free(h, false, dev, dev_cap);
     };
+    SwCtg *cg = reinterpret_cast<SwCtg *>(pin);
+    int32_t *rs = reinterpret_cast<int32_t *>(pin + b_ctg), *re = reinterpret_cast<int32_t *>(pin + b_ctg + b_i32);
+    uint32_t *rctg = reinterpret_cast<uint32_t *>(pin + b_ctg + 2 * b_i32);
+    for (uint32_t k = 0; k < n_sel; ++k) {
+        const uint32_t i = ctg_index[k];
+        const int32_t cs = chr_start[k];
+        const int64_t ce = (int64_t)cs + s->len[i] - 1;
+        cg[k] = SwCtg{s->off[i], s->len[i], cs, (int32_t)ce, (uint32_t)range_off[k], {0u, 0u}};
+        // utils.rs:151-156 slices seq[from-1..to): a range outside the ctg (or inverted) panics there
+        for (uint64_t q = range_off[k]; q < range_off[k + 1]; ++q) {
+            if (range_start[q] < cs || range_end[q] > ce || range_end[q] < range_start[q]) {
+                release();
+                return gams_fail(h, GAMS_EINVAL, "gpu_range_gc: range " + std::to_string(q - range_off[k]) +
+                                                     (n_sel > 1 ? " of selected ctg " + std::to_string(k) : std::string()) +
+                                                     " is not inside the ctg");
+            }
+            rs[q] = range_start[q];
+            re[q] = range_end[q];
+            rctg[q] = k;
+        }
+    }
+    int rc = gams_seqset_gcindex(h, s);
+    if (rc != GAMS_OK) {
+        release();
+        return rc;
+    }
+    e = gams_pool_alloc(h, false, in_bytes + b_i32, reinterpret_cast<void **>(&dev), &dev_cap);
+    if (e != hipSuccess) {
+        release();
+        return gams_fail(h, GAMS_ENOMEM, std::string("gpu_range_gc: device buffers: ") + hipGetErrorString(e));
+    }
 #define R_HIP(call)                                                                            \
     do {                                                                                       \
         hipError_t e_ = (call);                                                                \
         if (e_ != hipSuccess) {                                                                \
-            cleanup();                                                                         \
+            (void)hipStreamSynchronize(h->compute);                                            \
+            release();                                                                         \
             return gams_fail(h, GAMS_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
         }                                                                                      \
     } while (0)
-    R_HIP(hipMalloc(&d_rs, n * sizeof(int32_t)));
-    R_HIP(hipMalloc(&d_re, n * sizeof(int32_t)));
-    R_HIP(hipMalloc(&d_gc, n * sizeof(float)));
-    R_HIP(hipMemcpyAsync(d_rs, range_start, n * sizeof(int32_t), hipMemcpyHostToDevice, h->compute));
-    R_HIP(hipMemcpyAsync(d_re, range_end, n * sizeof(int32_t), hipMemcpyHostToDevice, h->compute));
+    R_HIP(hipMemcpyAsync(dev, pin, in_bytes, hipMemcpyHostToDevice, h->compute));
+    float *d_gc = reinterpret_cast<float *>(dev + in_bytes);
     SwArgs a{};
     a.pm = s->gcindex->d_pm;
     a.seg = s->gcindex->d_seg;
-    a.seq_off = s->off[i];
-    a.len = s->len[i];
-    a.chr_start = chr_start;
-    a.chr_end = chr_start + (int32_t)s->len[i] - 1;
+    a.ctgs = reinterpret_cast<const SwCtg *>(dev);
+    a.fctg = reinterpret_cast<const uint32_t *>(dev + b_ctg + 2 * b_i32);
     R_HIP(hipEventRecord(h->k0, h->compute));
-    hipLaunchKernelGGL(range_gc_kernel, dim3((n + 255) / 256), dim3(256), 0, h->compute, a, d_rs, d_re, n, d_gc);
+    hipLaunchKernelGGL(range_gc_kernel, dim3((n + 255) / 256), dim3(256), 0, h->compute, a,
+                       reinterpret_cast<const int32_t *>(dev + b_ctg), reinterpret_cast<const int32_t *>(dev + b_ctg + b_i32), n,
+                       d_gc);
     R_HIP(hipGetLastError());
     R_HIP(hipEventRecord(h->k1, h->compute));
     h->k_valid = true;
     h->kq_used = 0;
-    R_HIP(hipMemcpyAsync(gc, d_gc, n * sizeof(float), hipMemcpyDeviceToHost, h->compute));
+    R_HIP(hipMemcpyAsync(gc, d_gc, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->compute));
     R_HIP(hipStreamSynchronize(h->compute));
 #undef R_HIP
-    cleanup();
+    release();
     return GAMS_OK;
+}
+
+extern "C" int gams_gpu_range_gc(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, int32_t chr_start,
+                                 const int32_t *range_start, const int32_t *range_end, uint32_t n, float *gc) {
+    if (!h || !s || (n && (!range_start || !range_end || !gc)))
+        return gams_fail(h, GAMS_EINVAL, "gpu_range_gc: null argument");
+    const uint64_t range_off[2] = {0, n};
+    return gams_gpu_range_gc_batch(h, s, 1, &i, &chr_start, range_off, range_start, range_end, gc);
 }

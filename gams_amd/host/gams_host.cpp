@@ -1035,29 +1035,23 @@ std::map<std::string, std::vector<std::pair<Range, std::string>>> read_peak(Loca
     return peaks_of;
 }
 
-std::vector<Peak> peak_records(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq,
-                               const std::vector<std::pair<Range, std::string>> &peaks) {
+namespace {
+void peak_check_inside(const Ctg &ctg, const std::vector<std::pair<Range, std::string>> &peaks) {
+    for (const auto &pk : peaks)
+        if (pk.first.start < ctg.chr_start || pk.first.end > ctg.chr_end || pk.first.end < pk.first.start)
+            throw Error(GAMS_EINVAL, "peak: " + pk.first.to_string() + " is not inside " + ctg.id +
+                                         " (the reference panics on the slice, utils.rs:155)");
+}
+
+// the Peak records of one ctg from its merged ranges and their gc (peak.rs:65-158)
+std::vector<Peak> peak_fill(const Ctg &ctg, const std::vector<std::pair<Range, std::string>> &peaks, const float *gc) {
     std::vector<Peak> out(peaks.size());
     if (peaks.empty()) return out;
-    uint32_t len = (uint32_t)(ctg.chr_end - ctg.chr_start + 1);
-    SeqSetGuard sg{h};
-    check(h, gams_seqset_create(h, 1, &len, &sg.s));
-    check(h, gams_seqset_upload(h, sg.s, 0, seq));
-    std::vector<int32_t> rs(peaks.size()), re(peaks.size());
-    for (size_t i = 0; i < peaks.size(); ++i) {
-        rs[i] = peaks[i].first.start;
-        re[i] = peaks[i].first.end;
-        if (rs[i] < ctg.chr_start || re[i] > ctg.chr_end || re[i] < rs[i])
-            throw Error(GAMS_EINVAL, "peak: " + peaks[i].first.to_string() + " is not inside " + ctg.id +
-                                         " (the reference panics on the slice, utils.rs:155)");
-    }
-    std::vector<float> gc(peaks.size());
-    check(h, gams_gpu_range_gc(h, sg.s, 0, ctg.chr_start, rs.data(), re.data(), (uint32_t)peaks.size(), gc.data()));
     for (size_t i = 0; i < peaks.size(); ++i) {                         // peak.rs:65-95
         Peak &p = out[i];
         p.id = "peak:" + ctg.id + ":" + std::to_string(i + 1);
         p.range = peaks[i].first.to_string();
-        p.length = re[i] - rs[i] + 1;
+        p.length = peaks[i].first.end - peaks[i].first.start + 1;
         p.signal = peaks[i].second;
         p.gc = gc[i];
     }
@@ -1066,11 +1060,11 @@ std::vector<Peak> peak_records(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq
     float prev_gc = out.front().gc;
     int32_t prev_end = ctg.chr_start;
     for (size_t i = 0; i < out.size(); ++i) {
-        out[i].left_wave_length = rs[i] - prev_end + 1;
+        out[i].left_wave_length = peaks[i].first.start - prev_end + 1;
         out[i].left_amplitude = std::fabs(out[i].gc - prev_gc);
         out[i].left_signal = prev_signal;
         prev_signal = out[i].signal;
-        prev_end = re[i];
+        prev_end = peaks[i].first.end;
         prev_gc = out[i].gc;
     }
     // right (peak.rs:135-157)
@@ -1078,12 +1072,88 @@ std::vector<Peak> peak_records(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq
     float next_gc = out.back().gc;
     int32_t next_start = ctg.chr_end;
     for (size_t i = out.size(); i-- > 0;) {
-        out[i].right_wave_length = next_start - re[i] + 1;
+        out[i].right_wave_length = next_start - peaks[i].first.end + 1;
         out[i].right_amplitude = std::fabs(out[i].gc - next_gc);
         out[i].right_signal = next_signal;
         next_signal = out[i].signal;
-        next_start = rs[i];
+        next_start = peaks[i].first.start;
         next_gc = out[i].gc;
+    }
+    return out;
+}
+}  // namespace
+
+std::vector<Peak> peak_records(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq,
+                               const std::vector<std::pair<Range, std::string>> &peaks) {
+    if (peaks.empty()) return {};
+    peak_check_inside(ctg, peaks);
+    uint32_t len = (uint32_t)(ctg.chr_end - ctg.chr_start + 1);
+    SeqSetGuard sg{h};
+    check(h, gams_seqset_create(h, 1, &len, &sg.s));
+    check(h, gams_seqset_upload(h, sg.s, 0, seq));
+    std::vector<int32_t> rs(peaks.size()), re(peaks.size());
+    for (size_t i = 0; i < peaks.size(); ++i) {
+        rs[i] = peaks[i].first.start;
+        re[i] = peaks[i].first.end;
+    }
+    std::vector<float> gc(peaks.size());
+    check(h, gams_gpu_range_gc(h, sg.s, 0, ctg.chr_start, rs.data(), re.data(), (uint32_t)peaks.size(), gc.data()));
+    return peak_fill(ctg, peaks, gc.data());
+}
+
+// several ctgs: one seqset per batch of <= batch_bytes bases, the merged ranges of all of its ctgs through ONE
+// gams_gpu_range_gc_batch call (a ctg's few hundred ranges are one or two workgroups)
+std::vector<std::vector<Peak>> peak_records_batch(gams_gpu_t *h, const std::vector<Ctg> &ctgs,
+                                                  const std::vector<const uint8_t *> &seqs,
+                                                  const std::vector<std::vector<std::pair<Range, std::string>>> &peaks,
+                                                  uint64_t batch_bytes) {
+    if (ctgs.size() != seqs.size() || ctgs.size() != peaks.size())
+        throw Error(GAMS_EINVAL, "peak_records_batch: ctgs / seqs / peaks size mismatch");
+    std::vector<std::vector<Peak>> out(ctgs.size());
+    std::vector<size_t> todo;
+    for (size_t c = 0; c < ctgs.size(); ++c)
+        if (!peaks[c].empty()) {
+            peak_check_inside(ctgs[c], peaks[c]);
+            todo.push_back(c);
+        }
+    for (size_t b = 0; b < todo.size();) {
+        uint64_t bytes = 0;
+        size_t e = b;
+        while (e < todo.size()) {
+            const uint64_t len = (uint64_t)(ctgs[todo[e]].chr_end - ctgs[todo[e]].chr_start + 1);
+            if (e > b && bytes + len > batch_bytes) break;
+            bytes += len;
+            ++e;
+        }
+        const uint32_t n = (uint32_t)(e - b);
+        std::vector<uint32_t> lens(n), index(n);
+        std::vector<const uint8_t *> ptrs(n);
+        std::vector<int32_t> chr_start(n);
+        std::vector<uint64_t> off(n + 1, 0);
+        for (uint32_t k = 0; k < n; ++k) {
+            const Ctg &c = ctgs[todo[b + k]];
+            lens[k] = (uint32_t)(c.chr_end - c.chr_start + 1);
+            ptrs[k] = seqs[todo[b + k]];
+            index[k] = k;
+            chr_start[k] = c.chr_start;
+            off[k + 1] = off[k] + peaks[todo[b + k]].size();
+        }
+        std::vector<int32_t> rs(off[n]), re(off[n]);
+        for (uint32_t k = 0; k < n; ++k) {
+            const auto &pv = peaks[todo[b + k]];
+            for (size_t i = 0; i < pv.size(); ++i) {
+                rs[off[k] + i] = pv[i].first.start;
+                re[off[k] + i] = pv[i].first.end;
+            }
+        }
+        SeqSetGuard sg{h};
+        check(h, gams_seqset_create(h, n, lens.data(), &sg.s));
+        check(h, gams_seqset_upload_all(h, sg.s, ptrs.data()));
+        std::vector<float> gc(off[n]);
+        check(h, gams_gpu_range_gc_batch(h, sg.s, n, index.data(), chr_start.data(), off.data(), rs.data(), re.data(),
+                                         gc.data()));
+        for (uint32_t k = 0; k < n; ++k) out[todo[b + k]] = peak_fill(ctgs[todo[b + k]], peaks[todo[b + k]], gc.data() + off[k]);
+        b = e;
     }
     return out;
 }

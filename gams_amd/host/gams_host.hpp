@@ -166,6 +166,12 @@ std::map<std::string, std::vector<std::pair<Range, std::string>>> read_peak(Loca
 // right wavelength, amplitude and neighbour signal.  Serials start at 1 (a fresh cnt:peak:).
 std::vector<Peak> peak_records(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq,
                                const std::vector<std::pair<Range, std::string>> &peaks);
+// the same for several ctgs on one handle: one seqset and ONE gams_gpu_range_gc_batch call per batch of
+// <= batch_bytes bases; out[c] = the Peak records of ctgs[c]
+std::vector<std::vector<Peak>> peak_records_batch(gams_gpu_t *h, const std::vector<Ctg> &ctgs,
+                                                  const std::vector<const uint8_t *> &seqs,
+                                                  const std::vector<std::vector<std::pair<Range, std::string>>> &peaks,
+                                                  uint64_t batch_bytes = 256ull << 20);
 
 // src/cmd_gams/rg.rs:41-77 / feature.rs:47-95: the records the loaders SET, as (key, JSON) pairs in
 // the reference's order (ctg id order, then file order), serials from 1 per ctg (a fresh cnt:).

@@ -235,15 +235,23 @@ char *gams_host_peak(gams_gpu_t *h, uint32_t n, const char *const *ids, const ch
         gams::Locator loc(h, ctgs);
         auto peaks_of = gams::read_peak(loc, split_lines(lines));
         std::string out;
+        // ctgs in id order (the map's), all of their merged ranges through one batched call
+        std::vector<gams::Ctg> pc;
+        std::vector<const uint8_t *> ps;
+        std::vector<std::vector<std::pair<gams::Range, std::string>>> pp;
         for (auto &kv : peaks_of) {
             uint32_t slot = 0;
             while (slot < n && ctgs[slot].id != kv.first) ++slot;
-            for (const gams::Peak &p : gams::peak_records(h, ctgs[slot], seqs[slot], kv.second))
+            pc.push_back(ctgs[slot]);
+            ps.push_back(seqs[slot]);
+            pp.push_back(kv.second);
+        }
+        for (const std::vector<gams::Peak> &recs : gams::peak_records_batch(h, pc, ps, pp))
+            for (const gams::Peak &p : recs)
                 out += p.id + "\t" + p.range + "\t" + std::to_string(p.length) + "\t" + gams::fmt_f32(p.gc) + "\t" +
                        p.signal + "\t" + std::to_string(p.left_wave_length) + "\t" + gams::fmt_f32(p.left_amplitude) +
                        "\t" + p.left_signal + "\t" + std::to_string(p.right_wave_length) + "\t" +
                        gams::fmt_f32(p.right_amplitude) + "\t" + p.right_signal + "\n";
-        }
         return out;
     });
 }

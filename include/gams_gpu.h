@@ -229,6 +229,11 @@ int gams_gpu_sw_batch(gams_gpu_t *h, gams_seqset_t *s, uint32_t n_sel, const uin
 int gams_gpu_range_gc(gams_gpu_t *h, gams_seqset_t *s, uint32_t i, int32_t chr_start,
                       const int32_t *range_start, const int32_t *range_end, uint32_t n,
                       float *gc);
+/* The same for the ranges of several ctgs of the seqset in one launch (ctg_index / chr_start / range_off as in
+ * gams_gpu_sw_batch): gc[q] for range q of the concatenated list. */
+int gams_gpu_range_gc_batch(gams_gpu_t *h, gams_seqset_t *s, uint32_t n_sel, const uint32_t *ctg_index,
+                            const int32_t *chr_start, const uint64_t *range_off, const int32_t *range_start,
+                            const int32_t *range_end, float *gc);
 
 /* ---- sorted-interval index (replaces rust_lapper `idx:`) ---------------- */
 /* m intervals [start, stop) (stop = end+1, redis.rs:245-248,291-294) grouped

@@ -237,6 +237,28 @@ def test_upload_all_ragged_batch_matches_per_ctg_content(eng):
 
     for i, s in enumerate(seqs):
         check(i, s)
+    # gams_gpu_range_gc_batch: the ranges of several ctgs (skipped, repeated, out of order) in one launch
+    sel = [6, 1, 4, 1, 7]
+    per, rs_all, re_all = [], [], []
+    for i in sel:
+        n = len(seqs[i])
+        rs = rng.integers(1, n + 1, 50).astype(np.int32)
+        re = np.minimum(rs + rng.choice([0, 9, 99], rs.size), n).astype(np.int32)
+        gc = np.zeros(rs.size, np.float32)
+        eng.check(eng.lib.gams_gpu_range_gc(eng.h, ss.p, i, 1, rs.ctypes.data, re.ctypes.data, rs.size, gc.ctypes.data))
+        per.append(gc)
+        rs_all.append(rs)
+        re_all.append(re)
+    sel_a, cst = np.array(sel, np.uint32), np.ones(len(sel), np.int32)
+    roff = (np.arange(len(sel) + 1) * 50).astype(np.uint64)
+    rs_c, re_c = np.ascontiguousarray(np.concatenate(rs_all)), np.ascontiguousarray(np.concatenate(re_all))
+    gc = np.zeros(rs_c.size, np.float32)
+    eng.check(eng.lib.gams_gpu_range_gc_batch(eng.h, ss.p, len(sel), sel_a.ctypes.data, cst.ctypes.data, roff.ctypes.data,
+                                              rs_c.ctypes.data, re_c.ctypes.data, gc.ctypes.data))
+    assert np.array_equal(gc, np.concatenate(per))
+    re_c[60] = len(seqs[1]) + 5                                         # a range outside its ctg is reported
+    assert eng.lib.gams_gpu_range_gc_batch(eng.h, ss.p, len(sel), sel_a.ctypes.data, cst.ctypes.data, roff.ctypes.data,
+                                           rs_c.ctypes.data, re_c.ctypes.data, gc.ctypes.data) == _lib.EINVAL
     new = alphabet[rng.integers(0, 4, lens[2])].tobytes()
     ss.upload(2, new)
     check(2, new)
