@@ -378,6 +378,9 @@ extern "C" int gams_gpu_sw_batch(gams_gpu_t *h, gams_seqset_t *s, uint32_t n_sel
     const uint64_t nf64 = feat_off[n_sel];
     if (nf64 == 0) return GAMS_OK;
     if (!feat_start || !feat_end) return gams_fail(h, GAMS_EINVAL, "gpu_sw: null argument");
+    // one thread per (feature, slot); max beyond 2^24 windows a side cannot exist in a ctg of < 2^31 bases
+    // and would overflow the product
+    if (max > (1 << 24)) return gams_fail(h, GAMS_EUNSUPPORTED, "gpu_sw: max beyond 2^24 windows a side");
     const uint64_t threads = nf64 * (1u + 2u * (uint64_t)max);
     if (nf64 > 0xffffffffull || (threads + 255) / 256 > 0x7fffffffull)
         return gams_fail(h, GAMS_EUNSUPPORTED, "gpu_sw: too many feature slots for one launch");
