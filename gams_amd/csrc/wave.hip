@@ -214,8 +214,8 @@ void wave_fill_tiles_tapered(gams_wave_plan_t *p, uint32_t slots) {
     const uint64_t T = p->total_windows;
     // measurement knobs: % of a round of workgroup slots for the W = 4 / W = 8 tails (gpurun_out/r2_taper_sweep.log:
     // 384 Mb 71.6 us without tails, 70.0 at 50/50, 68.5 at 25/50, 70.9 at 100/100; the 120-Mb launch 28.4-28.7 for all)
-    static const int k4 = [] { const char *e = getenv("GAMS_TAPER4"); return e ? atoi(e) : 25; }();
-    static const int k8 = [] { const char *e = getenv("GAMS_TAPER8"); return e ? atoi(e) : 50; }();
+    const char *e4 = getenv("GAMS_TAPER4"), *e8 = getenv("GAMS_TAPER8");   // read per plan (tools/ab_plans.py)
+    const int k4 = e4 ? atoi(e4) : 25, k8 = e8 ? atoi(e8) : 50;
     const uint64_t x4 = std::min<uint64_t>((uint64_t)slots * k4 / 100 * tw4, T * 8 / 100);
     const uint64_t y8 = std::min<uint64_t>((uint64_t)slots * k8 / 100 * tw8, T * 17 / 100);
     p->tiles.clear();
