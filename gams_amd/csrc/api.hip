@@ -192,17 +192,30 @@ int gams_gpu_last_kernel_ms(gams_gpu_t *h, float *ms) {
 int gams_gpu_host_alloc(gams_gpu_t *h, uint64_t bytes, void **p) {
     if (!h || !p) return gams_fail(h, GAMS_EINVAL, "host_alloc: null argument");
     GAMS_HIP(h, hipSetDevice(h->device));
-    hipError_t e = hipHostMalloc(p, std::max<uint64_t>(bytes, 1), hipHostMallocDefault);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        return gams_fail(h, GAMS_ENOMEM, std::string("host_alloc: ") + hipGetErrorString(e));
-    }
+    // from the handle's pool of page-locked blocks: pinning 150 MB takes tens of milliseconds, a host that asks
+    // for the same columns batch after batch gets the block of the batch before
+    size_t cap = 0;
+    hipError_t e = gams_pool_alloc(h, true, (size_t)std::max<uint64_t>(bytes, 1), p, &cap);
+    if (e != hipSuccess) return gams_fail(h, GAMS_ENOMEM, std::string("host_alloc: ") + hipGetErrorString(e));
+    h->host_blocks.push_back({*p, cap});
     return GAMS_OK;
 }
 
 void gams_gpu_host_free(gams_gpu_t *h, void *p) {
-    if (h) (void)hipSetDevice(h->device);
-    if (p) (void)hipHostFree(p);
+    if (!p) return;
+    if (!h) {
+        (void)hipHostFree(p);
+        return;
+    }
+    (void)hipSetDevice(h->device);
+    for (size_t i = 0; i < h->host_blocks.size(); ++i)
+        if (h->host_blocks[i].p == p) {
+            const size_t cap = h->host_blocks[i].bytes;
+            h->host_blocks.erase(h->host_blocks.begin() + (long)i);
+            gams_pool_free(h, true, p, cap);
+            return;
+        }
+    (void)hipHostFree(p);   // not one of this handle's blocks
 }
 
 // ---------------------------------------------------------------------------

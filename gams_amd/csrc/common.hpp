@@ -50,6 +50,7 @@ struct gams_gpu {
         size_t bytes;
     };
     std::vector<Block> dev_pool, pin_pool;
+    std::vector<Block> host_blocks;   // page-locked blocks handed out by gams_gpu_host_alloc (their pooled sizes)
 };
 
 // Pooled allocation on the handle's device (pinned = page-locked host memory).  *cap is the size

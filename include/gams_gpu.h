@@ -71,6 +71,9 @@ int gams_gpu_last_kernel_ms(gams_gpu_t *h, float *ms);
  * move their columns in chunks (copy in, search, copy out on three streams); from page-locked arrays the
  * three overlap and a call runs at the rate of the PCIe link.  Any host memory works. */
 int gams_gpu_host_alloc(gams_gpu_t *h, uint64_t bytes, void **p);
+/* Blocks come from (and go back to) the handle's pool of page-locked memory, so asking for the same columns batch
+ * after batch does not pin them again.  Free with the handle that allocated, while it is alive (h == NULL: the
+ * block is released to the system; that is also the way to free one after its handle is gone). */
 void gams_gpu_host_free(gams_gpu_t *h, void *p);
 
 /* window.rs:78-94: number of size/step windows over `len` bases (-1: bad size/step) */

@@ -204,3 +204,24 @@ def test_index_from_idx_blobs(eng):
         sel = np.flatnonzero(qg == g)
         exp = np.searchsorted(st, qe[sel], "left") - np.searchsorted(st + 1, qs[sel].astype(np.int64) + 1, "left")
         assert np.array_equal(cnt[sel], exp), g
+
+
+def test_host_alloc_blocks_are_pooled(eng):
+    """gams_gpu_host_alloc / gams_gpu_host_free: a freed page-locked block is handed out again for the next request
+    of that size (no second pinning), blocks can be freed in any order and are writable / readable."""
+    import ctypes as C
+    lib = eng.lib
+    a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    eng.check(lib.gams_gpu_host_alloc(eng.h, 3 << 20, C.byref(a)))
+    eng.check(lib.gams_gpu_host_alloc(eng.h, 3 << 20, C.byref(b)))
+    assert a.value and b.value and a.value != b.value
+    C.memset(a, 0x5A, 3 << 20)
+    C.memset(b, 0xA5, 3 << 20)
+    assert C.string_at(a.value + (3 << 20) - 4, 4) == b"\x5a" * 4 and C.string_at(b, 4) == b"\xa5" * 4
+    first = a.value
+    lib.gams_gpu_host_free(eng.h, a)
+    eng.check(lib.gams_gpu_host_alloc(eng.h, 3 << 20, C.byref(c)))
+    assert c.value == first                                  # the block of before, not a new pinning
+    lib.gams_gpu_host_free(eng.h, b)
+    lib.gams_gpu_host_free(eng.h, c)
+    lib.gams_gpu_host_free(eng.h, None)

@@ -19,6 +19,7 @@ ap.add_argument("--step", type=int, default=10)
 ap.add_argument("--rounds", type=int, default=9)
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--lib", default=None, help="another build of libgams_gpu.so")
+ap.add_argument("--flight", action="store_true", help="the plans of an arm on lanes 0, 1, 2 (passes in flight, like bench.py's timed region)")
 args = ap.parse_args()
 
 eng = engine.Engine(0, lib=_lib.bind(os.path.abspath(args.lib), strict=False)) if args.lib else engine.Engine(0)
@@ -61,6 +62,9 @@ for arm in args.arms:
         if k.startswith("plan."):
             for p in ps:
                 getattr(p, "set_" + k[5:])(int(v))
+    if args.flight:
+        for j, p in enumerate(ps):
+            p.set_lane(j % 4)
     plans.append(Rot(ps))
     for k in env:
         del os.environ[k]
