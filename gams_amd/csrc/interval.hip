@@ -107,12 +107,26 @@ struct gams_index {
     size_t arena_bytes = 0;
 };
 
+// Cell record of the anno path, 64 B: everything a "covered bases up to x" lookup needs when x falls in cell b of the
+// group's grid (the grid of the `lo` directory, about one span per cell) -- the rank at the cell's edge, the span in
+// front of it with the covered bases before that one, and the next five spans inline.  One line per position instead
+// of a directory line, a search and a record line; a cell that starts more than five spans falls back to those.
+struct SpanCell {
+    uint64_t base;        // covered bases in the group's spans before span rank-1 (0 when rank == 0)
+    uint32_t rank;        // spans with lo < the cell's edge
+    int32_t plo, phi;     // span rank-1; plo > phi when there is none
+    int32_t lo[5], hi[5]; // spans rank .. rank+4 (unused entries past the group's end)
+    uint32_t pad;
+};
+static_assert(sizeof(SpanCell) == 64, "SpanCell is one 64-B record");
+
 struct gams_spans {
     uint32_t n_groups = 0;
     uint64_t m = 0;
     SpanGroup *d_groups = nullptr;
     SpanRec *d_rec = nullptr;        // one 16-B record per span: the search and its two follow-up reads share a line
     uint32_t *d_dir_lo = nullptr;
+    SpanCell *d_cells = nullptr;     // m + n_groups + 1 records: group g's cell b at off[g] + g + b (like its directory)
 };
 
 namespace {
@@ -281,8 +295,94 @@ __device__ __forceinline__ uint64_t covered_upto_below(const SpanRec *rec, const
     return covered_upto(rec, dir, G, g, x2, nullptr);
 }
 
+// covered positions <= x through the cell records; *cell_no receives the cell (so that a second position in the
+// same cell reuses the record), `ok` = false: the cell starts more than five spans, use covered_upto
+__device__ __forceinline__ uint64_t covered_cell(const SpanCell &c, uint32_t n, int32_t x, bool &ok) {
+    const uint32_t valid = min(5u, n - c.rank);
+    uint32_t t = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < 5u; ++u) t += (u < valid && c.lo[u] <= x) ? 1u : 0u;
+    ok = !(t == 5u && c.rank + 5u < n);
+    const bool has_pred = c.plo <= c.phi;
+    if (t == 0u) {
+        if (!has_pred) return 0;
+        const int32_t top = c.phi < x ? c.phi : x;
+        return c.base + (uint64_t)((int64_t)top - c.plo + 1);
+    }
+    uint64_t cum = c.base + (has_pred ? (uint64_t)((int64_t)c.phi - c.plo + 1) : 0ull);
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; ++u)
+        if (u + 1u < t) cum += (uint64_t)((int64_t)c.hi[u] - c.lo[u] + 1);
+    const int32_t lo = c.lo[t - 1u], hi = c.hi[t - 1u];
+    const int32_t top = hi < x ? hi : x;
+    return cum + (uint64_t)((int64_t)top - lo + 1);
+}
+
+// cell of position x in the group's grid; false: no span of the group has lo <= x (the answer is 0)
+__device__ __forceinline__ bool span_cell_of(const SpanGroup &G, int32_t x, uint32_t &b) {
+    const uint64_t key = (uint64_t)((uint32_t)x ^ 0x80000000u) + 1u;   // spans with lo <= x = biased keys < key
+    if (G.n == 0 || key <= (uint64_t)G.lo.key0) return false;
+    const uint64_t bb = (key - 1u - G.lo.key0) >> G.lo.shift;          // the cell x itself falls in
+    b = (uint32_t)(bb < G.lo.nb ? bb : G.lo.nb - 1u);                   // past the last cell: the last cell's spans
+    return true;
+}
+
+__device__ __forceinline__ SpanCell load_cell(const SpanCell *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    union {
+        uint4 v[4];
+        SpanCell c;
+    } u;
+    u.v[0] = q[0];
+    u.v[1] = q[1];
+    u.v[2] = q[2];
+    u.v[3] = q[3];
+    return u.c;
+}
+
+__global__ __launch_bounds__(256) void span_cell_kernel(const SpanGroup *groups, uint32_t n_groups, const SpanRec *rec,
+                                                        const uint32_t *dir, uint64_t slots, SpanCell *cells) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (j >= slots) return;
+    uint32_t lo = 0, hi = n_groups;                 // last group with off[g] + g <= j
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (groups[mid].off + mid <= j)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint32_t g = lo;
+    const SpanGroup G = groups[g];
+    const uint64_t b = j - (G.off + g);
+    if (G.n == 0 || b >= G.lo.nb) return;
+    const uint32_t rank = dir[j];                   // spans with biased lo < key0 + (b << shift)
+    const SpanRec *r = rec + G.off;
+    SpanCell c;
+    c.rank = rank;
+    c.pad = 0;
+    if (rank) {
+        const SpanRec p = r[rank - 1u];
+        c.base = p.cum;
+        c.plo = p.lo;
+        c.phi = p.hi;
+    } else {
+        c.base = 0;
+        c.plo = 1;
+        c.phi = 0;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 5u; ++u) {
+        const bool in = rank + u < G.n;
+        const SpanRec q = r[in ? rank + u : 0u];
+        c.lo[u] = in ? q.lo : 0;
+        c.hi[u] = in ? q.hi : 0;
+    }
+    cells[j] = c;
+}
+
 __global__ __launch_bounds__(256) void span_cover_kernel(const SpanGroup *groups, const SpanRec *rec,
-                                                         const uint32_t *dir, uint32_t n_groups,
+                                                         const uint32_t *dir, const SpanCell *cells, uint32_t n_groups,
                                                          const uint32_t *group, const int32_t *clip_lo,
                                                          const int32_t *clip_hi, const int32_t *qs,
                                                          const int32_t *qe, uint64_t nq, float *out) {
@@ -297,9 +397,27 @@ __global__ __launch_bounds__(256) void span_cover_kernel(const SpanGroup *groups
         uint64_t card = 0;
         if (H >= L) {
             const SpanGroup G = groups[g];
-            uint32_t rank_h;
-            const uint64_t upto_h = covered_upto(rec, dir, G, g, H, &rank_h);
-            const uint64_t upto_l = L > INT32_MIN ? covered_upto_below(rec, dir, G, g, L - 1, rank_h) : 0;
+            // one 64-B cell record per end of the range (the same record when both ends fall in one cell)
+            uint32_t bh = 0, bl = 0;
+            uint64_t upto_h = 0, upto_l = 0;
+            bool ok_h = true, ok_l = true;
+            const bool any_h = span_cell_of(G, H, bh);
+            const bool any_l = L > INT32_MIN && span_cell_of(G, L - 1, bl);
+            if (any_h) {
+                const SpanCell ch = load_cell(cells + G.off + g + bh);
+                upto_h = covered_cell(ch, G.n, H, ok_h);
+                if (any_l) {
+                    if (bl == bh)
+                        upto_l = covered_cell(ch, G.n, L - 1, ok_l);
+                    else
+                        upto_l = covered_cell(load_cell(cells + G.off + g + bl), G.n, L - 1, ok_l);
+                }
+            }
+            if (!(ok_h && ok_l)) {                     // a crowded cell: directory + search + walk
+                uint32_t rank_h;
+                upto_h = covered_upto(rec, dir, G, g, H, &rank_h);
+                upto_l = L > INT32_MIN ? covered_upto_below(rec, dir, G, g, L - 1, rank_h) : 0;
+            }
             card = upto_h - upto_l;
         }
         const int32_t total = (int32_t)((int64_t)e - s + 1);
@@ -782,6 +900,14 @@ int gams_spans_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
     hipError_t e = to_device(&sp->d_groups, groups.data(), groups.size());
     if (e == hipSuccess) e = to_device(&sp->d_rec, rec.data(), m);
     if (e == hipSuccess) e = to_device(&sp->d_dir_lo, dir.data(), dir.size());
+    const uint64_t slots = m + n_groups + 1;
+    if (e == hipSuccess) e = hipMalloc(&sp->d_cells, slots * sizeof(SpanCell));
+    if (e == hipSuccess && n_groups) {
+        hipLaunchKernelGGL(span_cell_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, h->compute, sp->d_groups,
+                           n_groups, sp->d_rec, sp->d_dir_lo, slots, sp->d_cells);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(h->compute);
+    }
     if (e != hipSuccess) {
         (void)hipGetLastError();
         gams_spans_destroy(h, sp);
@@ -801,6 +927,7 @@ void gams_spans_destroy(gams_gpu_t *h, gams_spans_t *sp) {
     (void)hipFree(sp->d_groups);
     (void)hipFree(sp->d_dir_lo);
     (void)hipFree(sp->d_rec);
+    (void)hipFree(sp->d_cells);
     delete sp;
 }
 
@@ -814,7 +941,7 @@ int gams_gpu_cover(gams_gpu_t *h, gams_spans_t *sp, const uint32_t *group, const
     const QCol cols[5] = {{group, 4}, {clip_lo, 4}, {clip_hi, 4}, {qs, 4}, {qe, 4}};
     return query_pipeline(h, nq, cols, 5, prop, sizeof(float), [&](void *const *d, void *d_out, uint64_t n, hipStream_t st) {
         hipLaunchKernelGGL(span_cover_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sp->d_groups, sp->d_rec,
-                           sp->d_dir_lo, sp->n_groups, static_cast<const uint32_t *>(d[0]),
+                           sp->d_dir_lo, sp->d_cells, sp->n_groups, static_cast<const uint32_t *>(d[0]),
                            static_cast<const int32_t *>(d[1]), static_cast<const int32_t *>(d[2]),
                            static_cast<const int32_t *>(d[3]), static_cast<const int32_t *>(d[4]), n,
                            static_cast<float *>(d_out));
