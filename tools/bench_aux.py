@@ -99,7 +99,13 @@ lo = np.concatenate(lo_all)
 hi = np.concatenate(hi_all)
 soff = np.array(soff, np.uint64)
 sp = C.c_void_p()
-eng.check(lib.gams_spans_create(eng.h, n_chr, soff.ctypes.data, lo.ctypes.data, hi.ctypes.data, C.byref(sp)))
+for rep in range(2):
+    if sp:
+        lib.gams_spans_destroy(eng.h, sp)
+    t0 = time.time()
+    eng.check(lib.gams_spans_create(eng.h, n_chr, soff.ctypes.data, lo.ctypes.data, hi.ctypes.data, C.byref(sp)))
+    t_sp = time.time() - t0
+print(f"spans_create ({lo.size} spans, {n_chr} groups): {t_sp * 1e3:.1f} ms")
 g = rng.integers(0, n_chr, nq).astype(np.uint32)
 s = rng.integers(1, 1_999_000_000, nq).astype(np.int32)
 e = (s + rng.integers(0, 2000, nq)).astype(np.int32)
