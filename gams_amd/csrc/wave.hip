@@ -180,11 +180,19 @@ void wave_squared_band(const gams_wave_params_t &p, const float g[4], float sq[6
 }
 
 // W of the baked instantiations of wave_fast_kernel (parameters in the instruction stream)
-bool wave_is_baked(const gams_wave_params_t &q, int w) {
+// 0: the parameters are arguments; 1: size, step and lag baked into the instruction stream (BASELINE's configurations);
+// 2: size and step baked, the lag an argument (`--lag N` next to the default size: the reference's own benchmark
+// runs 100 / 5 / 200 and 100 / 20 / 50, doc/benchmark/Atha.md:55,276-280)
+int wave_baked_kind(const gams_wave_params_t &q, int w) {
     const bool headline = q.size == 100 && q.step == 10 && q.lag == 100;   // every BASELINE step-10 config
     const bool step1 = q.size == 100 && q.step == 1 && q.lag == 100;       // BASELINE configs[3] (GRCh38, step 1)
-    return (headline && (w == 12 || w == 8 || w == 4)) || (step1 && (w == 28 || w == 20 || w == 12));
+    if ((headline && (w == 12 || w == 8 || w == 4)) || (step1 && (w == 28 || w == 20 || w == 12))) return 1;
+    if (q.size != 100 || q.lag + 1u > 128u * (uint32_t)w) return 0;        // at least half of the tile's slots are windows
+    if ((q.step == 5 || q.step == 10 || q.step == 20) && (w == 12 || w == 8 || w == 4)) return 2;
+    if (q.step == 1 && w == 20) return 2;
+    return 0;
 }
+bool wave_is_baked(const gams_wave_params_t &q, int w) { return wave_baked_kind(q, w) != 0; }
 
 size_t wave_fast_lds_bytes(uint32_t max_chunks, uint32_t w, uint32_t lag, bool dense) {
     size_t b = (size_t)((((max_chunks + 8u) >> 1) + 16u + 3u) & ~3u) * 4;   // BM: 16 mask bits per chunk + pad
@@ -267,7 +275,8 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
             const bool step1 = q.size == 100 && q.step == 1 && q.lag == 100;   // baked W = 20 fits 64 VGPRs
             const bool flight = p->depth >= 2;
             if (pick == 0 && w == 28 && step1 && tiles >= 4096) pick = w;
-            if (pick == 0 && w == 20 && step1 && tiles >= 1024) pick = w;
+            if (pick == 0 && w == 20 && (step1 || (q.size == 100 && q.step == 1 && wave_baked_kind(q, 20) == 2)) && tiles >= 1024)
+                pick = w;
             if (pick == 0 && w == 12 && tiles >= (flight ? 768u : 1536u)) pick = w;
             if (pick == 0 && w == 8 && tiles >= (flight ? 512u : 1024u)) pick = w;
             if (pick == 0 && w == 4) pick = w;
@@ -697,11 +706,30 @@ static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
         }
     }
     int rc = GAMS_OK;
-    const bool baked = p->fast_w && wave_is_baked(q, p->fast_w);
+    const int kind = p->fast_w ? wave_baked_kind(q, p->fast_w) : 0;
+    const bool baked = kind == 1;
     const bool step1 = baked && q.step == 1;
     if (p->direct)
         ;   // counted and decided above
-    else if (p->fast_w == 28)
+    else if (kind == 2) {
+        // size and step baked, lag from the arguments
+#define GAMS_RL(WW, ST) rc = wave_launch_fast<WW, 100, ST, 0>(h, p, a, st)
+        const int key = p->fast_w * 100 + q.step;
+        switch (key) {
+        case 405: GAMS_RL(4, 5); break;
+        case 805: GAMS_RL(8, 5); break;
+        case 1205: GAMS_RL(12, 5); break;
+        case 410: GAMS_RL(4, 10); break;
+        case 810: GAMS_RL(8, 10); break;
+        case 1210: GAMS_RL(12, 10); break;
+        case 420: GAMS_RL(4, 20); break;
+        case 820: GAMS_RL(8, 20); break;
+        case 1220: GAMS_RL(12, 20); break;
+        case 2001: GAMS_RL(20, 1); break;
+        default: rc = gams_fail(h, GAMS_ESTATE, "wave: no kernel for this tile size / step"); break;
+        }
+#undef GAMS_RL
+    } else if (p->fast_w == 28)
         rc = wave_launch_fast<28, 100, 1, 100>(h, p, a, st);   // baked only (wave_build_geometry)
     else if (p->fast_w == 20)
         rc = baked ? wave_launch_fast<20, 100, 1, 100>(h, p, a, st) : wave_launch_fast<20, 0, 0, 0>(h, p, a, st);
@@ -963,7 +991,8 @@ int gams_wave_plan_kernel_name(gams_gpu_t *h, gams_wave_plan_t *p, char *buf, si
     if (!h || !p || !buf || n == 0) return gams_fail(h, GAMS_EINVAL, "wave_plan_kernel_name: null argument");
     // the same decisions as wave_pass_on_way, spelled the way rocprofv3 prints the instantiation
     const gams_wave_params_t &q = p->prm;
-    const bool baked = p->fast_w && wave_is_baked(q, p->fast_w);
+    const int kind = p->fast_w ? wave_baked_kind(q, p->fast_w) : 0;
+    const bool baked = kind != 0;
     const char *nt = p->set->bytes > kStreamBytes ? "true" : "false";
     std::string name;
     if (p->serial)
@@ -973,7 +1002,7 @@ int gams_wave_plan_kernel_name(gams_gpu_t *h, gams_wave_plan_t *p, char *buf, si
     else if (p->taper)
         name = std::string("wave_fast_taper_kernel<100, 10, 100, ") + nt + ">";
     else if (p->fast_w) {
-        const std::string prm = baked ? "100, " + std::to_string(q.step) + ", 100, " : "0, 0, 0, ";
+        const std::string prm = baked ? "100, " + std::to_string(q.step) + (kind == 1 ? ", 100, " : ", 0, ") : "0, 0, 0, ";
         name = "wave_fast_kernel<" + std::to_string(p->fast_w) + ", " + prm + nt + ">";
     } else
         name = std::string("wave_tile_kernel<") + (p->k16 ? "unsigned short, " : "unsigned char, ") + (p->wide ? "true>" : "false>");

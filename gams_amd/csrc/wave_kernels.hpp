@@ -472,8 +472,8 @@ __device__ __forceinline__ void z_decide(float nf, float kkf, float S1f, float S
 // =============================================================================
 // __launch_bounds__(256, 8): 8 waves per SIMD = 8 workgroups per CU, i.e. at most 64 VGPRs.
 // Interleaved A/B (tools/ab.py) on 384 Mb: W = 12 runs 115 -> 105 us with the cap.
-// SIZE/STEP/LAG != 0 bake the headline parameters into the instruction stream (constant
-// bit-field offsets in phase 2); 0 = taken from the arguments at run time.
+// SIZE/STEP/LAG != 0 bake the parameters into the instruction stream (constant bit-field offsets in phase 2);
+// LAG == 0 with SIZE/STEP != 0: the lag stays an argument; all 0 = taken from the arguments at run time.
 template <int W, int SIZE, int STEP, int LAG, bool NT>
 // `tiles` and `seq` are kernel parameters of their own, in front of the argument block: with
 // -mllvm -amdgpu-kernarg-preload-count the command processor delivers the first kernel-argument
@@ -481,11 +481,13 @@ template <int W, int SIZE, int STEP, int LAG, bool NT>
 // the arguments first (two dependent round trips before a workgroup's first sequence load -> one).
 __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t *const seq_p, const WaveArgs &a) {
     static_assert(W % 4 == 0 && W <= 28 && (((W / 4) & 1) == 1 || W == 8), "W/4 odd (LDS bank stride), or W = 8 (64-bit reads); one mask bit per window");
-    static_assert((SIZE == 0) == (STEP == 0) && (SIZE == 0) == (LAG == 0), "bake all three or none");
+    static_assert((SIZE == 0) == (STEP == 0) && (LAG == 0 || STEP != 0), "bake size and step together; lag only with them");
     // Windows per tile.  Baked parameters: 256*W - LAG - 1, so that the tile's K slots (its windows
     // plus the lag+1 in front) are exactly 256*W: every thread of phase 2 owns W slots, which are
     // also the block of outgoing counts of the phase-3 thread with the same index.
-    constexpr uint32_t TW = STEP != 0 ? 256u * W - (uint32_t)LAG - 1u : 256u * W;
+    // (SIZE and STEP baked, LAG == 0: the lag is an argument -- `gams wave --lag N` keeps the baked kernel; the
+    // reference's own benchmark runs 100 / 5 / 200 and 100 / 20 / 50, doc/benchmark/Atha.md:55,276-280)
+    const uint32_t TW = STEP != 0 ? 256u * W - (LAG ? (uint32_t)LAG : a.lag) - 1u : 256u * W;
     constexpr int WD = W / 4;
     extern __shared__ __align__(16) unsigned char smem[];
     // LDS carve: BM (1 bit per base, 16 per chunk) | scratch (16 words) | K | PS | SG (dense only)
@@ -522,7 +524,7 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
         // Baked parameters: the tile never has more than NCH chunks, so every thread issues
         // all of its NLD loads back to back with no bounds logic (the bytes past the tile
         // are the next tile's or the seqset's tail slack), classifies, and stores.
-        constexpr uint32_t NCH = ((uint32_t)TW * STEP + ((uint32_t)LAG + 1u) * STEP + SIZE + 30u) / 16u + 1u;
+        constexpr uint32_t NCH = (256u * W * STEP + SIZE + 30u) / 16u + 1u;   // TW + lag + 1 = 256 * W windows' worth
         constexpr uint32_t NLD = (NCH + 255u) / 256u;
         uint4 v[NLD];
         // The tile's first row holds the halo (the previous tile's last 1.1 KB) and its last row the bytes
@@ -577,7 +579,7 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
         // offset: ~6 VALU per window, no LDS access inside the run, counts stored 4 per dword.
         if (vb >= 0) {
             counted = true;
-            constexpr uint32_t NK_MAX = (uint32_t)LAG + 1u + TW;     // = 256 * W
+            constexpr uint32_t NK_MAX = 256u * W;                    // = lag + 1 + TW
             constexpr uint32_t RUN = (uint32_t)W;
             static_assert(NK_MAX == 256u * RUN, "phase 2: W slots per thread");
             constexpr uint32_t NBITS = RUN * (uint32_t)STEP + (uint32_t)SIZE;
@@ -709,19 +711,38 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
             // each, consecutive lanes on consecutive entries) plus LAG % W counts straight from K.
             if (counted) {
                 summed = true;
-                constexpr uint32_t FULL = (uint32_t)LAG / (uint32_t)W, REM = (uint32_t)LAG % (uint32_t)W;
+                if constexpr (LAG != 0) {
+                    constexpr uint32_t FULL = (uint32_t)LAG / (uint32_t)W, REM = (uint32_t)LAG % (uint32_t)W;
 #pragma unroll
-                for (uint32_t j = 0; j < FULL; ++j) {
-                    const uint2 ps = PS[tid + j];
-                    S1 += ps.x;
-                    S2 += ps.y;
-                }
+                    for (uint32_t j = 0; j < FULL; ++j) {
+                        const uint2 ps = PS[tid + j];
+                        S1 += ps.x;
+                        S2 += ps.y;
+                    }
 #pragma unroll
-                for (uint32_t d = 0; d < (REM + 3u) / 4u; ++d) {
-                    uint32_t x = KW[bw + FULL * (uint32_t)WD + d];
-                    if (d == REM / 4u && (REM & 3u)) x &= (1u << (8u * (REM & 3u))) - 1u;
-                    S1 = __builtin_amdgcn_udot4(x, 0x01010101u, S1, false);
-                    S2 = __builtin_amdgcn_udot4(x, x, S2, false);
+                    for (uint32_t d = 0; d < (REM + 3u) / 4u; ++d) {
+                        uint32_t x = KW[bw + FULL * (uint32_t)WD + d];
+                        if (d == REM / 4u && (REM & 3u)) x &= (1u << (8u * (REM & 3u))) - 1u;
+                        S1 = __builtin_amdgcn_udot4(x, 0x01010101u, S1, false);
+                        S2 = __builtin_amdgcn_udot4(x, x, S2, false);
+                    }
+                } else {
+                    // the lag is an argument: the same sums with run-time trip counts.  A thread that owns windows
+                    // of the tile never reaches past block 255 (t + lag / W <= 255); threads behind the tile's
+                    // last window are masked off and read a clamped entry.
+                    const uint32_t full = lag / (uint32_t)W, rem = lag % (uint32_t)W;
+                    for (uint32_t j = 0; j < full; ++j) {
+                        const uint2 ps = PS[min(tid + j, 271u)];
+                        S1 += ps.x;
+                        S2 += ps.y;
+                    }
+                    const uint32_t rd = (rem + 3u) >> 2;
+                    for (uint32_t d = 0; d < rd; ++d) {
+                        uint32_t x = KW[bw + full * (uint32_t)WD + d];
+                        if (d == (rem >> 2) && (rem & 3u)) x &= (1u << (8u * (rem & 3u))) - 1u;
+                        S1 = __builtin_amdgcn_udot4(x, 0x01010101u, S1, false);
+                        S2 = __builtin_amdgcn_udot4(x, x, S2, false);
+                    }
                 }
             }
         }

@@ -626,3 +626,43 @@ def test_plan_kernel_name_follows_the_plan(eng):
     assert names[(50, 7, 33, 1.0)] == "wave_fast_kernel<4, 0, 0, 0, false>"
     assert names[(100, 10, 100, 0.5)] == "wave_serial_wave_kernel"
     assert names[(100, 1000, 100, 1.0)].startswith("wave_direct_count_kernel")
+
+
+@pytest.mark.parametrize("step", [1, 5, 10, 20])
+def test_size_and_step_baked_lag_as_argument(eng, s288c, step):
+    """size 100 with step 1 / 5 / 10 / 20 and ANY lag keeps the baked kernel (lag is an argument there; the
+    reference's own benchmark runs 100 / 5 / 200 and 100 / 20 / 50, doc/benchmark/Atha.md:55,276-280): counts,
+    signals and peaks against the oracle for lags around every boundary of the tile layout, at every tile size
+    that has such a kernel, on ragged ctgs."""
+    pool = [bytes(s288c["I"][:120_000]), synth(41_234, 5).tobytes(), bytes(s288c["Mito"][:9_000]), synth(3_777, 6).tobytes()]
+    tiles = (5120,) if step == 1 else (1024, 2048, 3072)
+    lags = [2, 3, 5, 11, 50, 99, 101, 200, 255, 511]
+    seen = set()
+    for tile in tiles:
+        w = tile // 256
+        for lag in lags + [128 * w - 1, 128 * w]:             # the last two: just inside / outside the baked form
+            # (a ctg with fewer windows than the lag is refused like the reference's panic, stat.rs:30)
+            seqs = [sq for sq in pool if (len(sq) - 100) // step + 1 >= lag]
+            if not seqs:
+                continue
+            ss = engine.SeqSet(eng, seqs)
+            for thr in (3.0,) if lag not in (50, 200) else (3.0, 1.5):
+                try:
+                    plan = engine.WavePlan(eng, ss, 100, step, lag, thr, 1.0, flags=_lib.WAVE_PEAKS | _lib.WAVE_DENSE,
+                                           tile_windows=tile)
+                except _lib.GamsError as e:
+                    assert e.code == _lib.EUNSUPPORTED, (step, lag, tile)
+                    continue
+                seen.add(plan.kernel_name())
+                plan.run()
+                pk = plan.peaks()
+                for c, sq in enumerate(seqs):
+                    ocnt, _, osig = ora.wave_windows(sq, 100, step, lag, thr, 1.0)
+                    cnt, sig = plan.dense(c)
+                    assert np.array_equal(cnt, ocnt) and np.array_equal(sig.astype(np.int32), osig), (step, lag, tile, c)
+                    mine = pk[pk["ctg"] == c]
+                    idx = np.flatnonzero(osig)
+                    assert np.array_equal(mine["window"], idx) and np.array_equal(mine["signal"], osig[idx]), (step, lag, tile, c)
+                plan.close()
+            ss.close()
+    assert any(f", 100, {step}, 0, " in k for k in seen), seen     # the lag-as-argument instantiations did run
