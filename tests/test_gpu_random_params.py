@@ -38,6 +38,7 @@ def random_seq(rng, n):
 
 # GAMS_FUZZ_SEEDS=first:count widens the sweep (profiles/r01_fuzz_log.txt: 122,000 seeds)
 _FIRST, _COUNT = (int(x) for x in os.environ.get("GAMS_FUZZ_SEEDS", "0:64").split(":"))
+_SIZE100 = os.environ.get("GAMS_FUZZ_SIZE100", "") == "1"   # size 100, step 1 / 5 / 10 / 20, any lag in 2..599
 
 
 @pytest.mark.parametrize("seed", range(_FIRST, _FIRST + _COUNT))
@@ -48,6 +49,8 @@ def test_random_parameters(eng, seed):
     lag = int(rng.choice([2, 3, 10, 33, 50, 100, 100, 127, 128, 200, 400]))
     thr = float(rng.choice([0.5, 1.0, 2.0, 2.5, 3.0, 3.0, 3.5, 5.0]))
     infl = float(rng.choice([1.0, 1.0, 1.0, 1.0, 0.5, 0.0]))
+    if _SIZE100:                                   # the kernels with size and step baked and the lag as an argument
+        size, step, lag = 100, int(rng.choice([1, 5, 10, 20])), int(rng.integers(2, 600))
     n_ctg = int(rng.integers(1, 5))
     need = size + (lag + 5) * step
     seqs = [random_seq(rng, int(need + rng.integers(0, 40 * need // 10 + 5000))) for _ in range(n_ctg)]
