@@ -729,10 +729,12 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
                 } else {
                     // the lag is an argument: the same sums with run-time trip counts.  A thread that owns windows
                     // of the tile never reaches past block 255 (t + lag / W <= 255); threads behind the tile's
-                    // last window are masked off and read a clamped entry.
+                    // last window are masked off and stop at the array's end.
                     const uint32_t full = lag / (uint32_t)W, rem = lag % (uint32_t)W;
-                    for (uint32_t j = 0; j < full; ++j) {
-                        const uint2 ps = PS[min(tid + j, 271u)];
+                    const uint32_t trips = min(full, 272u - tid);     // (masked threads: stay inside PS)
+#pragma unroll 4
+                    for (uint32_t j = 0; j < trips; ++j) {
+                        const uint2 ps = PS[tid + j];
                         S1 += ps.x;
                         S2 += ps.y;
                     }
