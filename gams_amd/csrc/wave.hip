@@ -189,7 +189,7 @@ int wave_baked_kind(const gams_wave_params_t &q, int w) {
     if ((headline && (w == 12 || w == 8 || w == 4)) || (step1 && (w == 28 || w == 20 || w == 12))) return 1;
     if (q.size != 100 || q.lag + 1u > 128u * (uint32_t)w) return 0;        // at least half of the tile's slots are windows
     if ((q.step == 5 || q.step == 10 || q.step == 20) && (w == 12 || w == 8 || w == 4)) return 2;
-    if (q.step == 1 && w == 20) return 2;
+    if ((q.step == 1 || q.step == 5) && w == 20) return 2;   // 5120 windows x 5 bases: the bytes of a W = 10 tile at step 10
     return 0;
 }
 bool wave_is_baked(const gams_wave_params_t &q, int w) { return wave_baked_kind(q, w) != 0; }
@@ -277,6 +277,9 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
             if (pick == 0 && w == 28 && step1 && tiles >= 4096) pick = w;
             if (pick == 0 && w == 20 && (step1 || (q.size == 100 && q.step == 1 && wave_baked_kind(q, 20) == 2)) && tiles >= 1024)
                 pick = w;
+            // step 5: twice the windows per byte of step 10, W = 20 amortises the per-thread work (384 Mb: 112 -> 108 us at
+            // lag 100, 131 -> 114 us at lag 200, one seqset)
+            if (pick == 0 && w == 20 && q.size == 100 && q.step == 5 && wave_baked_kind(q, 20) == 2 && tiles >= 2048) pick = w;
             if (pick == 0 && w == 12 && tiles >= (flight ? 768u : 1536u)) pick = w;
             if (pick == 0 && w == 8 && tiles >= (flight ? 512u : 1024u)) pick = w;
             if (pick == 0 && w == 4) pick = w;
@@ -726,6 +729,7 @@ static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
         case 820: GAMS_RL(8, 20); break;
         case 1220: GAMS_RL(12, 20); break;
         case 2001: GAMS_RL(20, 1); break;
+        case 2005: GAMS_RL(20, 5); break;
         default: rc = gams_fail(h, GAMS_ESTATE, "wave: no kernel for this tile size / step"); break;
         }
 #undef GAMS_RL
