@@ -200,7 +200,7 @@ size_t wave_fast_lds_bytes(uint32_t max_chunks, uint32_t w, uint32_t lag, bool d
     b += (256u * w + lag + 1u + 31u) & ~15u;             // K (threads past the tile's end still read their slots)
     b += 272 * 8;                                        // PS: block sums of the baked kernels
     b += 256 * 2;                                        // RK: ranks of phase 4b
-    if (dense) b += (256u * w + 15u) & ~15u;             // SG
+    if (dense) b += ((256u * w + 15u) & ~15u) + 16u;     // SG (+ the dword behind the last group, read with it)
     return (b + 15) & ~(size_t)15;
 }
 

@@ -893,9 +893,32 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
                 SG[base + q] = (uint8_t)(((crest >> q) & 1u) | (((trough >> q) & 1u) ? 0xFFu : 0u));
         }
         __syncthreads();
-        for (uint32_t idx = tid; idx < nvalid; idx += 256u) {
-            a.dense_cnt[cg.win_base + w0 + idx] = K[idx + lag + 1u];
-            a.dense_sig[cg.win_base + w0 + idx] = (int8_t)SG[idx];
+        // Rows leave four windows per thread: a 16-B store of four counts and a 4-B store of four signals, on
+        // groups aligned in the GLOBAL row index (the tile's first row sits anywhere); the bytes come out of LDS
+        // as two dwords + v_alignbyte.  The up to three rows in front of the first aligned group and behind the
+        // last one are stored one by one.  (One row per thread and trip -- a 4-B and a 1-B store per window --
+        // cost 155 us of a 476-us pass over 3.8e8 windows at step 1.)
+        const uint64_t g0 = cg.win_base + w0;
+        const uint32_t head = min((uint32_t)(0u - (uint32_t)g0) & 3u, nvalid);
+        const uint32_t ngrp = (nvalid - head) >> 2;
+        const uint32_t *SW = reinterpret_cast<const uint32_t *>(SG);
+        for (uint32_t j = tid; j < ngrp; j += 256u) {
+            const uint32_t idx = head + 4u * j;
+            const uint32_t ka = idx + lag + 1u;
+            const uint32_t kc = __builtin_amdgcn_alignbyte(KW[(ka >> 2) + 1u], KW[ka >> 2], ka & 3u);
+            const uint32_t sc = __builtin_amdgcn_alignbyte(SW[(idx >> 2) + 1u], SW[idx >> 2], idx & 3u);
+            *reinterpret_cast<uint4 *>(a.dense_cnt + g0 + idx) =
+                make_uint4(kc & 0xFFu, (kc >> 8) & 0xFFu, (kc >> 16) & 0xFFu, kc >> 24);
+            *reinterpret_cast<uint32_t *>(a.dense_sig + g0 + idx) = sc;
+        }
+        const uint32_t tail0 = head + 4u * ngrp;
+        if (tid < head) {
+            a.dense_cnt[g0 + tid] = K[tid + lag + 1u];
+            a.dense_sig[g0 + tid] = (int8_t)SG[tid];
+        } else if (tid >= 64u && tail0 + (tid - 64u) < nvalid) {   // (another wave than the head's)
+            const uint32_t idx = tail0 + (tid - 64u);
+            a.dense_cnt[g0 + idx] = K[idx + lag + 1u];
+            a.dense_sig[g0 + idx] = (int8_t)SG[idx];
         }
     }
 
