@@ -189,6 +189,7 @@ int wave_baked_kind(const gams_wave_params_t &q, int w) {
     if ((headline && (w == 12 || w == 8 || w == 4)) || (step1 && (w == 28 || w == 20 || w == 12))) return 1;
     if (q.size != 100 || q.lag + 1u > 128u * (uint32_t)w) return 0;        // at least half of the tile's slots are windows
     if ((q.step == 5 || q.step == 10 || q.step == 20) && (w == 12 || w == 8 || w == 4)) return 2;
+    if (q.step == 1 && w == 28) return 2;
     if ((q.step == 1 || q.step == 5) && w == 20) return 2;   // 5120 windows x 5 bases: the bytes of a W = 10 tile at step 10
     return 0;
 }
@@ -247,7 +248,7 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
     // fast kernel: 8-bit counts, 32-bit variance math with 24-bit multiplies
     const bool fast_ok = !p->serial && q.size <= 255 && q.step <= 32 && (uint64_t)q.lag * q.size <= 65535 &&
                          (uint64_t)q.lag * q.size * q.size < (1ull << 24) && q.lag >= 2;
-    const bool step1_prm = q.size == 100 && q.step == 1 && q.lag == 100;
+    const bool step1_prm = q.size == 100 && q.step == 1 && wave_baked_kind(q, 28) != 0;
     if (fast_ok && (tw_req == 0 || tw_req == 1024 || tw_req == 2048 || tw_req == 3072 || tw_req == 5120 ||
                     (tw_req == 7168 && step1_prm))) {
         static const int cand[5] = {28, 20, 12, 8, 4};
@@ -274,7 +275,8 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
             const uint64_t tiles = p->total_windows / tw;
             const bool step1 = q.size == 100 && q.step == 1 && q.lag == 100;   // baked W = 20 fits 64 VGPRs
             const bool flight = p->depth >= 2;
-            if (pick == 0 && w == 28 && step1 && tiles >= 4096) pick = w;
+            if (pick == 0 && w == 28 && (step1 || (q.size == 100 && q.step == 1 && wave_baked_kind(q, 28) == 2)) && tiles >= 4096)
+                pick = w;
             if (pick == 0 && w == 20 && (step1 || (q.size == 100 && q.step == 1 && wave_baked_kind(q, 20) == 2)) && tiles >= 1024)
                 pick = w;
             // step 5: twice the windows per byte of step 10, W = 20 amortises the per-thread work (384 Mb: 112 -> 108 us at
@@ -732,6 +734,7 @@ static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
         case 1220: GAMS_RL(12, 20); break;
         case 2001: GAMS_RL(20, 1); break;
         case 2005: GAMS_RL(20, 5); break;
+        case 2801: GAMS_RL(28, 1); break;
         default: rc = gams_fail(h, GAMS_ESTATE, "wave: no kernel for this tile size / step"); break;
         }
 #undef GAMS_RL

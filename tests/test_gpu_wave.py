@@ -635,7 +635,7 @@ def test_size_and_step_baked_lag_as_argument(eng, s288c, step):
     signals and peaks against the oracle for lags around every boundary of the tile layout, at every tile size
     that has such a kernel, on ragged ctgs."""
     pool = [bytes(s288c["I"][:120_000]), synth(41_234, 5).tobytes(), bytes(s288c["Mito"][:9_000]), synth(3_777, 6).tobytes()]
-    tiles = (5120,) if step == 1 else (1024, 2048, 3072, 5120) if step == 5 else (1024, 2048, 3072)
+    tiles = (5120, 7168) if step == 1 else (1024, 2048, 3072, 5120) if step == 5 else (1024, 2048, 3072)
     lags = [2, 3, 5, 11, 50, 99, 101, 200, 255, 511]
     seen = set()
     for tile in tiles:
