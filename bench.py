@@ -80,16 +80,11 @@ def build_batches(name, rank, world, copies, scale):
         lengths = [max(20000, int(x * scale)) for x in lengths]
     prm = dict(size=size, step=step, lag=lag, threshold=3.0, influence=1.0)
     if scaling == "strong":
-        # ONE genome; every rank cuts the same ctgs and keeps its LPT share (wave.rs:288-299: the ctg is
-        # the unit of work)
-        ctgs = synth.genome_ctgs(lengths, piece, first_chr_index=1)
-        weights = [window_count(len(c["seq"]), size, step) for c in ctgs]
-        owner = shard.lpt_assign(weights, world)
-        mine = [c for c, o in zip(ctgs, owner) if o == rank]
-        loads = [sum(w for w, o in zip(weights, owner) if o == r) for r in range(world)]
-        note = (f"{len(ctgs)} ctgs LPT-sharded x{world} by windows; rank loads max/mean "
-                f"{max(loads) / (sum(loads) / world):.4f}")
-        del ctgs
+        # ONE genome.  Its layout is closed form, ownership (LPT by window count; wave.rs:288-299: the ctg
+        # is the unit of work) is decided on the layout, and a rank generates only the ctgs it owns
+        mine, loads, n_ctgs = synth.sharded_genome_ctgs(lengths, piece, rank, world, size, step)
+        note = (f"{n_ctgs} ctgs LPT-sharded x{world} by windows; rank loads max/mean "
+                f"{max(loads) / (sum(loads) / world):.4f}; rank {rank} generated its own {len(mine)} ctgs only")
         return [mine], prm, sum(lengths), "strong", note
     # weak: world * copies genomes of the same shape; the unit handed to a rank is a genome (its
     # chromosomes are seeded by the genome's index, so a rank generates only what it owns)
@@ -228,6 +223,38 @@ def secondary_metrics(eng):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks as
+    children -- `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` -- BEFORE
+    this process has imported torch or loaded the library (a process that has touched the GPU must never
+    exec or re-launch), relay the children's output (rank 0 prints the one JSON line) and return their
+    exit code.  The rendezvous is on 127.0.0.1 at a port the kernel just handed out."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL needs it)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["MASTER_PORT"] = str(port)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # the ranks' stdout is relayed line by line: JSON lines (rank 0's result) to stdout, anything else
+    # (gloo's connection chatter in a rehearsal) to stderr, so stdout stays the ONE line the contract asks for
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    try:
+        for line in proc.stdout:
+            dst = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+            dst.write(line)
+            dst.flush()
+        return proc.wait()
+    except KeyboardInterrupt:
+        proc.terminate()
+        return 130
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,28 +273,59 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the S288c / beyond-L3 extra measurements")
     ap.add_argument("--no-secondary", action="store_true", help="skip the sw / interval metrics")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="join the ranks, run the bench's three collectives once, print a JSON line and stop "
+                         "(no GPU work: checks the launch path)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started as plain `python bench.py --gpus N`: be our own launcher (see self_launch)
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     import torch
 
     dist = None
     n_dev = torch.cuda.device_count()
     device = local_rank % max(n_dev, 1)
-    backend = os.environ.get("GAMS_BENCH_BACKEND", "nccl")   # "gloo": rehearsal with several ranks on one GPU
-    if world > 1:
+    # RCCL needs one device per rank; with fewer devices than ranks (a rehearsal of the N > 1 path on a
+    # one-GPU box) the barrier and the two scalar reductions go over gloo instead -- nothing else changes,
+    # there is no collective on the data path.  GAMS_BENCH_BACKEND overrides.
+    backend = os.environ.get("GAMS_BENCH_BACKEND") or ("nccl" if n_dev >= world else "gloo")
+    force_dist = os.environ.get("GAMS_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ   # N = 1 through RCCL (test)
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
-        torch.cuda.set_device(device)
+        if n_dev:
+            torch.cuda.set_device(device)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend)
+    if args.rendezvous_only:
+        # plumbing check of the N > 1 entry path (runs without a GPU too): every rank joins, one barrier,
+        # one MAX and one SUM reduction -- the only collectives of the whole bench -- then rank 0 reports
+        got = None
+        if dist is not None:
+            red_dev = "cuda" if backend == "nccl" else "cpu"
+            dist.barrier()
+            t = torch.tensor([float(rank)], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            w = torch.tensor([1.0], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(w, op=dist.ReduceOp.SUM)
+            got = [float(t.item()), float(w.item())]
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"rendezvous": "ok", "n_gpus": world, "backend": backend if dist is not None else None,
+                              "max_rank_sum_ranks": got, "devices_visible": n_dev}), flush=True)
+        return
 
     from gams_amd import _lib, engine
 
@@ -384,6 +442,8 @@ def main():
                 "sharding": shard_note,
                 "device": arch,
                 "parallelism": f"ctg-sharded x{world}, no collective on the data path",
+                "collectives": (f"{backend}: barrier + MAX(time) + SUM(windows) around the timed region"
+                                if dist is not None else "none (one rank)"),
             },
             "roofline": {
                 "bound": "hbm",

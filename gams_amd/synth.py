@@ -120,16 +120,15 @@ def genome_ctgs(lengths, piece, seed=SEED, first_chr_index=1, workers=None):
     return [c for part in parts for c in part]
 
 
-def layout_ctg_lengths(lengths, piece, min_len=5000):
-    """Lengths of the ctgs `genome_ctgs` cuts, from the planted 10-kb N runs alone (one per 20 Mb)
-    and the --piece rule of gen.rs:108-126 -- no bases generated.  Short N runs (1-49 bp) are
-    filled by `gen`; two of them abutting into a run of 50 or more (which would split a ctg) is
-    rare and ignored here, so this is the layout a sharding test can use at full GRCh38 size."""
+def layout_ctgs(lengths, piece, min_len=5000, first_chr_index=1):
+    """The ctgs `gen` cuts from chromosomes whose only ctg-splitting N runs are the planted 10-kb ones
+    (one per 20 Mb), by the --piece rule of gen.rs:108-126 -- no bases generated.
+    -> list of (chr_index, serial, chr_start, chr_end), 1-based inclusive, in `gen` order."""
     out = []
-    for length in lengths:
+    for k, length in enumerate(lengths):
         cuts = []
-        for k in range(1, length // 20_000_000 + 1):
-            s = k * 20_000_000 - 5000
+        for j in range(1, length // 20_000_000 + 1):
+            s = j * 20_000_000 - 5000
             if s + 10000 < length:
                 cuts.append((s + 1, s + 10000))            # 1-based inclusive N run
         regions, pos = [], 1
@@ -137,6 +136,7 @@ def layout_ctg_lengths(lengths, piece, min_len=5000):
             regions.append((pos, a - 1))
             pos = b + 1
         regions.append((pos, length))
+        serial = 0
         for lo, hi in regions:
             if hi - lo + 1 < min_len:
                 continue
@@ -148,8 +148,86 @@ def layout_ctg_lengths(lengths, piece, min_len=5000):
                 cur.append([p0, hi])
             else:
                 cur[-1][1] = hi
-            out += [e - s + 1 for s, e in cur]
+            for s, e in cur:
+                serial += 1
+                out.append((first_chr_index + k, serial, s, e))
     return out
+
+
+def layout_ctg_lengths(lengths, piece, min_len=5000):
+    """Lengths of the ctgs `genome_ctgs` cuts, from the planted 10-kb N runs alone (one per 20 Mb)
+    and the --piece rule of gen.rs:108-126 -- no bases generated.  Short N runs (1-49 bp) are
+    filled by `gen`; two of them abutting into a run of 50 or more (which would split a ctg) is
+    rare and ignored here, so this is the layout a sharding test can use at full GRCh38 size."""
+    return [e - s + 1 for _, _, s, e in layout_ctgs(lengths, piece, min_len)]
+
+
+_N_SLOT = 4096      # ctg_bases: at most one short N run per slot, at least 64 bp from the slot's edges
+
+
+def ctg_bases(chr_index, chr_start, length, seed=SEED):
+    """The bases of ONE ctg of a synthetic genome whose layout is `layout_ctgs`: a function of
+    (seed, chromosome, start) alone, so a rank generates exactly the ctgs it owns (bench.py strong
+    scaling; the ctg is the unit of work, wave.rs:288-299).  Same composition as `chromosome`
+    (p(x) on the chromosome coordinate, ~20 % soft-masked runs, short N runs at 1e-5 / bp); the N
+    runs sit one per 4096-bp slot, 64 bp clear of the slot's edges, so no two of them merge into a
+    run of 50 (which would split the ctg) and none touches the ctg's ends: `gen` over the assembled
+    chromosome gives back exactly the layout (tests/test_shard_gloo.py)."""
+    rng = np.random.default_rng([seed, chr_index, chr_start])
+    out = np.empty(length, np.uint8)
+    for b in range(0, length, _CHUNK):
+        e = min(b + _CHUNK, length)
+        x = np.arange(chr_start - 1 + b, chr_start - 1 + e, dtype=np.float64)
+        p = 0.38 + 0.06 * np.sin(2 * np.pi * x / 2300.0) + 0.04 * np.sin(2 * np.pi * x / 97000.0)
+        is_gc = rng.random(e - b) < p
+        pick = rng.integers(0, 2, e - b, dtype=np.uint8)
+        out[b:e] = np.where(is_gc, np.where(pick, 0x47, 0x43), np.where(pick, 0x41, 0x54)).astype(np.uint8)
+    n_runs = max(1, int(length * 0.20 / 300))
+    starts = rng.integers(0, length, n_runs)
+    lens = rng.geometric(1.0 / 300.0, n_runs)
+    mark = np.zeros(length + 1, np.int32)
+    np.add.at(mark, starts, 1)
+    np.add.at(mark, np.minimum(starts + lens, length), -1)
+    out[np.cumsum(mark[:-1]) > 0] |= 0x20
+    n_slots = length // _N_SLOT
+    n_n = min(int(rng.poisson(length * 1e-5)), n_slots)
+    if n_n:
+        slots = rng.choice(n_slots, n_n, replace=False)
+        offs = rng.integers(64, _N_SLOT - 64 - 49, n_n)
+        for s, ln in zip((slots * _N_SLOT + offs).tolist(), rng.integers(1, 50, n_n).tolist()):
+            out[s:s + ln] = 0x4E
+    return out
+
+
+def sharded_genome_ctgs(lengths, piece, rank=0, world=1, size=100, step=10, seed=SEED, first_chr_index=1,
+                        workers=None):
+    """Strong-scaling genome: the layout is closed form (`layout_ctgs`), ownership is decided on it
+    (LPT by window count), and only the owned ctgs' bases are generated.
+    -> (this rank's ctg dicts in genome order, rank loads in windows, number of ctgs in the genome)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    from . import shard
+
+    lay = layout_ctgs(lengths, piece, first_chr_index=first_chr_index)
+    weights = [max(0, (e - s + 1 - size) // step + 1) for _, _, s, e in lay]
+    owner = shard.lpt_assign(weights, world)
+    loads = [0] * world
+    for w, o in zip(weights, owner):
+        loads[o] += w
+    mine = [c for c, o in zip(lay, owner) if o == rank]
+
+    def one(c):
+        k, serial, s, e = c
+        return dict(id=f"ctg:{k}:{serial}", chr_id=str(k), chr_start=s, chr_end=e,
+                    seq=ctg_bases(k, s, e - s + 1, seed))
+
+    if workers is None:
+        workers = min(16, os.cpu_count() or 1)
+    if workers <= 1 or len(mine) < 2:
+        return [one(c) for c in mine], loads, len(lay)
+    with ThreadPoolExecutor(workers) as ex:
+        return list(ex.map(one, mine)), loads, len(lay)
 
 
 def point_features(ctgs, n, seed=SEED + 1):
