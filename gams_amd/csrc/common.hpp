@@ -8,6 +8,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/gams_gpu.h"
@@ -51,7 +52,23 @@ struct gams_gpu {
     };
     std::vector<Block> dev_pool, pin_pool;
     std::vector<Block> host_blocks;   // page-locked blocks handed out by gams_gpu_host_alloc (their pooled sizes)
+    // hipFuncAttributeMaxDynamicSharedMemorySize belongs to the kernel FUNCTION (per device), not to a plan:
+    // the largest value any launch on this handle has asked for, per function; only ever raised (gams_lds_attr)
+    std::unordered_map<const void *, size_t> lds_attr;
+    std::mutex lds_mu;
 };
+
+// Make sure launches of `func` on the handle's device may use `bytes` of dynamic LDS.  Plans with different
+// tile sizes / lags share one kernel function; lowering the attribute behind another plan's back would fail
+// that plan's next launch, so the recorded maximum only grows.
+inline hipError_t gams_lds_attr(gams_gpu_t *h, const void *func, size_t bytes) {
+    std::lock_guard<std::mutex> lk(h->lds_mu);
+    size_t &have = h->lds_attr[func];
+    if (bytes <= have) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
 
 // Pooled allocation on the handle's device (pinned = page-locked host memory).  *cap is the size
 // of the block handed out (>= bytes); pass it back to gams_pool_free.

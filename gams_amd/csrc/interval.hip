@@ -52,7 +52,7 @@ struct IndexGroup {
     uint32_t n;       // intervals in the group
     uint32_t maxlen;  // max(stop - start), Lapper::max_len
     KeyDir start, stop;       // one bucket per key, rank only (locate's lower bound)
-    KeyDir bk_start, bk_stop; // ~four keys per bucket, rank + the next seven keys inline (count's two lower bounds)
+    KeyDir bk_start, bk_stop; // ~2^kCellShift keys per cell, rank + the next seven keys inline (count's two lower bounds)
 };
 
 // What a count query needs of its group, one 32-B record (the 80-B IndexGroup costs a second line and
@@ -67,7 +67,7 @@ struct CountGroup {
 // Bucket record of the count path: everything a lower bound needs in ONE 32-B access -- the rank of
 // the first key at or after the bucket's edge and the seven keys that follow it (0xffffffff past the
 // group's end).  A key that falls in bucket b is compared with those seven; only when all seven are
-// smaller (a bucket of more than seven keys: 5 % of uniform buckets) the search goes on in the key
+// smaller (a cell of more than seven keys: 0.1 % of uniform cells at 2 keys per cell) the search goes on in the key
 // array.  Random queries are bound by scattered lines out of the Infinity Cache: the separate
 // directory + key array of the locate path cost two lines per bound, this one.
 struct BkRec {
@@ -99,8 +99,8 @@ struct gams_index {
     uint32_t *d_lstart = nullptr;    // per group, starts of the (start,stop)-sorted pairs: ascending (both searches)
     IvRec *d_lrec = nullptr;         // the sorted pairs + the caller's index of each, 16 B (locate's scan)
     uint32_t *d_dir_start = nullptr; // m + n_groups entries: group g's directory begins at off[g] + g (locate)
-    BkRec *d_bk_start = nullptr;     // 2 * (m/4 + 2*n_groups + 2) records, the starts' and the stops' record of a cell side by side;
-    BkRec *d_bk_stop = nullptr;      // = d_bk_start + 1; group g's cells begin at off[g]/4 + 2g
+    BkRec *d_bk_start = nullptr;     // 2 * ((m >> kCellShift) + 2*n_groups + 2) records, the starts' and the stops' record of a cell side by side;
+    BkRec *d_bk_stop = nullptr;      // = d_bk_start + 1; group g's cells begin at (off[g] >> kCellShift) + 2g
     CountGroup *d_cgroups = nullptr;
     // everything above lives in one pooled HBM block
     uint8_t *arena = nullptr;
@@ -451,9 +451,12 @@ __device__ __forceinline__ KeyDir dir_params(uint32_t first, uint32_t last, uint
     KeyDir d{0u, 0u, 0u, 0u};
     if (n == 0) return d;
     d.key0 = first;
-    const uint32_t range = last - first;
-    while ((range >> d.shift) >= n) ++d.shift;     // (range >> shift) + 1 <= n buckets
-    d.nb = (range >> d.shift) + 1u;
+    // 64-bit range: a one-key grid (n == 1, e.g. the cell grid of a one-interval group [0, 2^31 + 1)) needs
+    // range >> shift == 0, i.e. shift == 32 when the range has bit 31 set -- a 32-bit shift by 32 is masked
+    // to 0 on this hardware and the loop would never end.  Every consumer shifts in 64 bits.
+    const uint64_t range = (uint64_t)last - (uint64_t)first;
+    while ((range >> d.shift) >= n) ++d.shift;     // (range >> shift) + 1 <= n buckets; ends at shift <= 32
+    d.nb = (uint32_t)(range >> d.shift) + 1u;
     return d;
 }
 
@@ -573,9 +576,9 @@ KeyDir build_dir(const uint32_t *keys, uint32_t n, uint32_t *dir) {
         return d;
     }
     d.key0 = keys[0];
-    const uint32_t range = keys[n - 1] - keys[0];
-    while ((range >> d.shift) >= n) ++d.shift;     // (range >> shift) + 1 <= n buckets
-    d.nb = (range >> d.shift) + 1u;
+    const uint64_t range = (uint64_t)keys[n - 1] - (uint64_t)keys[0];
+    while ((range >> d.shift) >= n) ++d.shift;     // (range >> shift) + 1 <= n buckets; ends at shift <= 32
+    d.nb = (uint32_t)(range >> d.shift) + 1u;
     uint32_t i = 0;
     for (uint32_t b = 0; b < d.nb; ++b) {
         const uint64_t edge = (uint64_t)d.key0 + ((uint64_t)b << d.shift);

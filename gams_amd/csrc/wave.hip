@@ -447,8 +447,7 @@ template <typename KT, bool WIDE>
 int wave_launch(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a, hipStream_t st) {
     auto kern = wave_tile_kernel<KT, WIDE>;
     if (!p->attr_set) {
-        GAMS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+        GAMS_HIP(h, gams_lds_attr(h, reinterpret_cast<const void *>(kern), p->lds_bytes));
         p->attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)p->tiles.size()), dim3(256), p->lds_bytes, st, a);
@@ -460,8 +459,7 @@ template <int W, int SIZE, int STEP, int LAG, bool NT>
 int wave_launch_fast_nt(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a, hipStream_t st) {
     auto kern = wave_fast_kernel<W, SIZE, STEP, LAG, NT>;
     if (!p->attr_set) {
-        GAMS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+        GAMS_HIP(h, gams_lds_attr(h, reinterpret_cast<const void *>(kern), p->lds_bytes));
         p->attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)p->tiles.size()), dim3(256), p->lds_bytes, st, a.tiles, a.seq, a);
@@ -482,8 +480,7 @@ template <bool NT>
 int wave_launch_taper(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a, hipStream_t st) {
     auto kern = wave_fast_taper_kernel<100, 10, 100, NT>;
     if (!p->attr_set) {
-        GAMS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+        GAMS_HIP(h, gams_lds_attr(h, reinterpret_cast<const void *>(kern), p->lds_bytes));
         p->attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)p->tiles.size()), dim3(256), p->lds_bytes, st, a.tiles, a.seq, a);
@@ -767,8 +764,7 @@ static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
         if (q.lag + 1u <= kSerialRing) {
             // one wavefront per ctg, the last lag + 1 filtered values in an LDS ring
             const size_t ring = (size_t)((q.lag + 1u + 63u) & ~63u) * sizeof(float);
-            GAMS_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void *>(wave_serial_wave_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kSerialRing * sizeof(float))));
+            GAMS_HIP(h, gams_lds_attr(h, reinterpret_cast<const void *>(wave_serial_wave_kernel), kSerialRing * sizeof(float)));
             hipLaunchKernelGGL(wave_serial_wave_kernel, dim3(n), dim3(64), ring, st, p->d_ctgs, n, w.d_dense_cnt,
                                w.d_dense_sig, q.lag, q.threshold, q.influence, (float)q.size);
         } else {
@@ -1088,6 +1084,14 @@ int gams_wave_peaks(gams_gpu_t *h, gams_wave_plan_t *p, const gams_peak_t **peak
         GAMS_HIP(h, hipStreamSynchronize(h->readback));
         const uint64_t total = h->pin_scratch[0];
         const uint64_t worst = h->pin_scratch[1];
+        // Buffers below are sized from these two device-written words: refuse values no pass over this
+        // plan can produce (a tile signals at most its own windows, all tiles together at most the
+        // batch's) instead of allocating and copying by them.
+        if (worst > p->tw || total > p->total_windows || total > (uint64_t)nt * worst)
+            return gams_fail(h, GAMS_EHIP,
+                             "wave_peaks: inconsistent peak counts from the device (total " + std::to_string(total) +
+                                 ", fullest tile " + std::to_string(worst) + ", " + std::to_string(p->total_windows) +
+                                 " windows in " + std::to_string(nt) + " tiles of at most " + std::to_string(p->tw) + ")");
         if (worst > p->tile_cap) {
             // some tile signalled more windows than its slot holds: the device has reported the
             // fullest tile (runs are deterministic, so that is what the slots need -- at GRCh38 step 1 a

@@ -134,10 +134,12 @@ std::string bincode_ctg_bundle(const std::vector<Ctg> &ctgs) {
 std::vector<Ctg> bincode_ctg_bundle_decode(const uint8_t *bytes, size_t n) {
     Reader r{bytes, n};
     const uint64_t cnt = r.count(8 + 8 * 4 + 12);
-    std::vector<Ctg> out;
-    out.reserve((size_t)cnt);
+    // bincode hands the entries to BTreeMap one by one: any order is accepted, a repeated key keeps the
+    // LAST value, and iteration (what get_bundle_ctg's callers see, redis.rs:216-233) is in key order.  The
+    // map is keyed by the stored KEY; the reference writes key == id, but nothing in the format says so.
+    std::map<std::string, Ctg> by_key;
     for (uint64_t i = 0; i < cnt; ++i) {
-        const std::string key = r.str();
+        std::string key = r.str();
         Ctg c;
         c.id = r.str();
         c.range = r.str();
@@ -146,11 +148,11 @@ std::vector<Ctg> bincode_ctg_bundle_decode(const uint8_t *bytes, size_t n) {
         c.chr_end = (int32_t)r.u32();
         c.chr_strand = r.str();
         c.length = (int32_t)r.u32();
-        if (!out.empty() && !(out.back().id < key))
-            throw Error(GAMS_EINVAL, "bincode: BTreeMap keys not strictly ascending at entry " + std::to_string(i));
-        (void)key;   // get_bundle_ctg keeps the map keyed by the stored key; the reference writes key == id
-        out.push_back(std::move(c));
+        by_key.insert_or_assign(std::move(key), std::move(c));
     }
+    std::vector<Ctg> out;
+    out.reserve(by_key.size());
+    for (auto &kv : by_key) out.push_back(std::move(kv.second));
     if (r.at != n) throw Error(GAMS_EINVAL, "bincode: " + std::to_string(n - r.at) + " trailing bytes after the map");
     return out;
 }

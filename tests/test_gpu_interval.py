@@ -225,3 +225,34 @@ def test_host_alloc_blocks_are_pooled(eng):
     lib.gams_gpu_host_free(eng.h, b)
     lib.gams_gpu_host_free(eng.h, c)
     lib.gams_gpu_host_free(eng.h, None)
+
+
+def test_one_interval_group_wider_than_2_31(eng):
+    """A group holding ONE interval whose stop - start has bit 31 set (idx:ctg of a one-ctg chromosome with
+    absurd coordinates; the C ABI takes any u32): the count path's one-cell grid needs a shift of 32, which
+    the directory builder has to reach in 64-bit arithmetic (a 32-bit `>> 32` never ends the loop
+    on this hardware).  Expected values: Lapper semantics in closed form."""
+    cases = [(0, 0x80000001), (5, 0xFFFFFFFE), (0x7FFFFFFF, 0xFFFFFFFF), (0, 0x7FFFFFFF)]
+    starts = np.array([c[0] for c in cases], np.uint32)
+    stops = np.array([c[1] for c in cases], np.uint32)
+    off = np.arange(len(cases) + 1, dtype=np.uint64)
+    ix = C.c_void_p()
+    eng.check(eng.lib.gams_index_create(eng.h, len(cases), off.ctypes.data, starts.ctypes.data, stops.ctypes.data,
+                                        C.byref(ix)))
+    qs = np.array([0, 1, 0x7FFFFFFF, 0x80000000, 0x80000001, 0xFFFFFFF0, 4, 5], np.uint32)
+    qe = (qs.astype(np.uint64) + np.array([1, 10, 2, 1, 5, 8, 1, 1])).clip(max=2**32 - 1).astype(np.uint32)
+    for g, (a, b) in enumerate(cases):
+        qg = np.full(qs.size, g, np.uint32)
+        cnt = np.full(qs.size, -9, np.int32)
+        hit = np.full(qs.size, -9, np.int64)
+        eng.check(eng.lib.gams_gpu_count(eng.h, ix, qg.ctypes.data, qs.ctypes.data, qe.ctypes.data, qs.size,
+                                         cnt.ctypes.data))
+        eng.check(eng.lib.gams_gpu_locate(eng.h, ix, qg.ctypes.data, qs.ctypes.data, qe.ctypes.data, qs.size,
+                                          hit.ctypes.data))
+        # Lapper: an interval [a, b) overlaps the query [s, e) iff a < e and b > s
+        exp = ((a < qe.astype(np.int64)) & (b > qs.astype(np.int64))).astype(np.int32)
+        assert np.array_equal(cnt, exp), (g, cnt, exp)
+        assert np.array_equal(hit, np.where(exp == 1, g, -1)), (g, hit)
+        for q in range(qs.size):
+            assert cnt[q] == ora.lapper_count(np.array([a], np.uint32), np.array([b], np.uint32), int(qs[q]), int(qe[q]))
+    eng.lib.gams_index_destroy(eng.h, ix)

@@ -666,3 +666,30 @@ def test_size_and_step_baked_lag_as_argument(eng, s288c, step):
                 plan.close()
             ss.close()
     assert any(f", 100, {step}, 0, " in k for k in seen), seen     # the lag-as-argument instantiations did run
+
+
+def test_plans_sharing_a_kernel_function_keep_their_lds(eng, s288c):
+    """The dynamic-LDS limit is an attribute of the kernel FUNCTION, not of a plan: plan A (lag 250:
+    more K slots) launches, then plan B (lag 20, same instantiation <W,100,10,0>), then A again -- A's second
+    launch still has its LDS and the same peaks.  Same for the general tile kernel, whose tiles differ far more
+    (size 300 / lag 210 against size 300 / lag 10)."""
+    seq = bytes(s288c["I"][:150_000])
+    ss = engine.SeqSet(eng, [seq, synth(60_000, 91).tobytes()])
+    for big, small in (((100, 10, 250), (100, 10, 20)), ((300, 7, 210), (300, 7, 10))):
+        a = engine.WavePlan(eng, ss, big[0], big[1], big[2], 3.0, 1.0, flags=_lib.WAVE_PEAKS)
+        b = engine.WavePlan(eng, ss, small[0], small[1], small[2], 3.0, 1.0, flags=_lib.WAVE_PEAKS)
+        assert a.kernel_name() == b.kernel_name()
+        a.run()
+        first = a.peaks().copy()
+        b.run()
+        pb = b.peaks().copy()
+        a.run()
+        again = a.peaks()
+        assert np.array_equal(first, again)
+        for plan, pk, prm in ((a, first, big), (b, pb, small)):
+            for c, sq in enumerate((seq, synth(60_000, 91).tobytes())):
+                _, _, osig = ora.wave_windows(sq, prm[0], prm[1], prm[2], 3.0, 1.0)
+                assert np.array_equal(pk[pk["ctg"] == c]["window"], np.flatnonzero(osig)), (prm, c)
+        a.close()
+        b.close()
+    ss.close()

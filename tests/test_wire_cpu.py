@@ -49,10 +49,19 @@ def test_ctg_bundle_rejects_damaged_input(cut):
         host.bincode_ctg_bundle_decode(bad)
 
 
-def test_ctg_bundle_rejects_unsorted_keys_and_huge_lengths():
+def test_ctg_bundle_decodes_like_a_btreemap_and_rejects_huge_lengths():
+    """bincode feeds the entries to BTreeMap::insert: any order is accepted, a repeated KEY keeps the last
+    value, iteration is in key order (what get_bundle_ctg's callers see, src/libs/redis.rs:216-233)."""
     a, b = ctg_bytes(CTGS[0]), ctg_bytes(CTGS[2])
-    with pytest.raises(host.HostError):
-        host.bincode_ctg_bundle_decode(struct.pack("<Q", 2) + a + b)            # ctg:I:2 before ctg:I:1
+    tsv = host.bincode_ctg_bundle_decode(struct.pack("<Q", 2) + a + b)          # ctg:I:2 before ctg:I:1
+    assert tsv == host.tsv_ctgs([CTGS[2], CTGS[0]])
+    # same key twice: the later entry wins -- judged on the stored key, not on the value's id
+    later = dict(CTGS[0], chr_start=100002)
+    dup = s("ctg:I:2") + ctg_bytes(later)[len(s("ctg:I:2")):]
+    assert host.bincode_ctg_bundle_decode(struct.pack("<Q", 3) + a + b + dup) == host.tsv_ctgs([CTGS[2], later])
+    # a key that differs from its value's id orders the entry
+    renamed = s("ctg:A") + ctg_bytes(CTGS[0])[len(s("ctg:I:2")):]
+    assert host.bincode_ctg_bundle_decode(struct.pack("<Q", 2) + b + renamed) == host.tsv_ctgs([CTGS[0], CTGS[2]])
     with pytest.raises(host.HostError):
         host.bincode_ctg_bundle_decode(struct.pack("<Q", 2**60) + a)
     with pytest.raises(host.HostError):
