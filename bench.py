@@ -289,6 +289,16 @@ def main():
     if world != args.gpus:
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                  f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+    # stdout carries ONE line, rank 0's JSON: everything else this process or its libraries print there
+    # (RCCL's version banner at the first collective, gloo's connection chatter) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     import torch
 
     dist = None
@@ -323,8 +333,8 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"rendezvous": "ok", "n_gpus": world, "backend": backend if dist is not None else None,
-                              "max_rank_sum_ranks": got, "devices_visible": n_dev}), flush=True)
+            emit({"rendezvous": "ok", "n_gpus": world, "backend": backend if dist is not None else None,
+                  "max_rank_sum_ranks": got, "devices_visible": n_dev})
         return
 
     from gams_amd import _lib, engine
@@ -538,7 +548,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_secondary:
         out["secondary"] = secondary_metrics(eng)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     eng.close()
     if dist is not None:
         dist.barrier()
