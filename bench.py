@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-ROUND = "r02"
+ROUND = "r03"
 
 WORKLOADS = {
     # name: (chromosome lengths, piece, size, step, lag, scaling for N > 1)
@@ -54,16 +54,19 @@ def profiled_traffic(workload):
     """HBM bytes per launch of the wave kernel from the committed rocprofv3 PMC passes
     (profiles/*_pmc.json, made by tools/prof.sh): FETCH_SIZE and WRITE_SIZE are in KiB and were
     collected in separate passes; on gfx950 FETCH_SIZE counts half the bytes of a wide coalesced
-    stream, so it is doubled (MI355X_MICROARCH.md, HBM section).  None if no profile matches."""
-    for rnd in (ROUND, "r01"):
-        path = os.path.join(ROOT, "profiles", f"{rnd}_{workload}_wave_pmc.json")
+    stream, so it is doubled (MI355X_MICROARCH.md, HBM section).  -> (bytes, the file they come from);
+    (None, None) if no profile matches.  PMC passes cannot run inside the timed process (they need
+    rocprofv3 around it and serialise dispatches), so this is a committed measurement of the same
+    command, not a live one -- `traffic_source` in the JSON line says which."""
+    for rnd in (ROUND, "r02", "r01"):
+        rel = os.path.join("profiles", f"{rnd}_{workload}_wave_pmc.json")
         try:
-            with open(path) as fh:
+            with open(os.path.join(ROOT, rel)) as fh:
                 p = json.load(fh)
-            return (2.0 * p["FETCH_SIZE"]["mean"] + p["WRITE_SIZE"]["mean"]) * 1024.0
+            return (2.0 * p["FETCH_SIZE"]["mean"] + p["WRITE_SIZE"]["mean"]) * 1024.0, rel
         except (OSError, KeyError, ValueError):
             continue
-    return None
+    return None, None
 
 
 def window_count(n, size, step):
@@ -123,6 +126,49 @@ def cpu_baseline(ctgs, prm, budget_windows=6_000_000, min_seconds=10.0):
             break
     dt = time.perf_counter() - t0
     return done / dt, used, done, results, passes, dt
+
+
+def end_to_end(eng, ctgs, prm, reps=4):
+    """PCIe-inclusive truth beside `value` (never `value`): one batch = every ctg of one genome of the workload,
+    through the host operator gams::wave_proc_ctgs(_gz) -- the seam of wave.rs:121-215 -- from (a) the gzip'd
+    `seq:` values as the store holds them (redis.rs:142-161) and (b) gunzipped host buffers, to the TSV text.
+    Per form: the best whole call of `reps` (host clock inside the C++ layer), and the stages of one call run
+    with the device drained at every stage boundary."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from gams_amd import host
+
+    T = max(1, min(16, os.cpu_count() or 1))        # inflate workers: the box's CPU share for one GPU
+    hc = [dict(id=c["id"], chr_id=c["chr_id"], chr_start=c["chr_start"], chr_end=c["chr_end"], seq=c["seq"]) for c in ctgs]
+    with ThreadPoolExecutor(T) as ex:               # flate2 Compression::fast = zlib level 1 (redis.rs:149-154)
+        for c, gz in zip(hc, ex.map(lambda c: host.encode_gz(bytes(c["seq"])), hc)):
+            c["gz"] = gz
+    windows = sum(window_count(len(c["seq"]), prm["size"], prm["step"]) for c in hc)
+    bases = sum(len(c["seq"]) for c in hc)
+    kw = dict(size=prm["size"], step=prm["step"], lag=prm["lag"], threshold=prm["threshold"], influence=prm["influence"])
+    out = {"workload": f"{len(hc)} ctgs, {bases} bases, {windows} windows: one batch, text of every ctg returned",
+           "gz_bytes": int(sum(len(c["gz"]) for c in hc))}
+    texts = []
+    for tag, fn in (("from_gz_seq_values", lambda sync: host.wave_gz(eng, hc, threads=T, sync=sync, **kw)),
+                    ("from_gunzipped_buffers", lambda sync: host.wave_timed(eng, hc, sync=sync, **kw))):
+        fn(False)                                   # first call: page-locks the image / staging blocks (pooled after)
+        best, text = None, None
+        for _ in range(reps):
+            text, st = fn(False)
+            if best is None or st["total_ms"] < best["total_ms"]:
+                best = st
+        _, staged = fn(True)
+        texts.append(text)
+        keep = ("inflate_upload_ms", "upload_ms", "plan_ms", "kernel_ms", "peaks_ms", "format_ms", "total_ms")
+        out[tag] = {"total_ms": best["total_ms"], "windows_per_s": windows / (best["total_ms"] * 1e-3),
+                    "sequence_GBps": bases / (best["total_ms"] * 1e-3) / 1e9,
+                    "rows": text.count(b"\n"), "text_bytes": len(text), "peaks": best["peaks"],
+                    "stages_ms_device_drained_per_stage": {k: staged[k] for k in keep if staged[k] > 0 or k == "total_ms"}}
+        if tag == "from_gz_seq_values":
+            out[tag]["inflate_threads"] = best["inflate_threads"]
+            out[tag]["inflate"] = "libdeflate.so.0 (dlopen) or zlib, one ctg per worker at a time, into a page-locked image; DMA follows the workers"
+    out["same_text_both_forms"] = texts[0] == texts[1]
+    return out
 
 
 def secondary_metrics(eng):
@@ -273,6 +319,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the S288c / beyond-L3 extra measurements")
     ap.add_argument("--no-secondary", action="store_true", help="skip the sw / interval metrics")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (gz / host buffers -> TSV text) block")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="join the ranks, run the bench's three collectives once, print a JSON line and stop "
                          "(no GPU work: checks the launch path)")
@@ -415,7 +462,31 @@ def main():
     kernel_name = plans[0].kernel_name()   # the instantiation this leg launched (rocprofv3's row of the same name)
     serial_windows = sum(win_per_batch[i % nb] for i in range(serial_steps)) / serial_steps
 
+    # run + peaks, pipelined: what a host that consumes the peaks pays per batch (wave.rs:157-214 reads them).
+    # Batch j runs on lane j; while its kernel is in flight the oldest batch's peaks are packed on the device
+    # (wave_offsets_kernel + wave_gather_kernel on the readback stream) and fetched into page-locked memory.
+    pass_with_peaks_ms = None
+    if world == 1 and nb > 1:
+        set_flight(True)
+        for p in plans:
+            p.set_pipelined(True)
+        for i in range(2 * nb):
+            plans[i % nb].run()
+            plans[(i + 1) % nb].peaks_count() if i >= nb - 1 else None
+        eng.sync()
+        k_steps = max(args.steps, 60)
+        t0 = time.perf_counter()
+        for i in range(k_steps):
+            plans[i % nb].run()
+            plans[(i + 1) % nb].peaks_count()          # the batch queued nb - 1 steps ago
+        eng.sync()
+        pass_with_peaks_ms = (time.perf_counter() - t0) / k_steps * 1e3
+        for p in plans:
+            p.set_pipelined(False)
+        set_flight(False)
+
     out = None
+    traffic, traffic_src = profiled_traffic(args.workload) if args.scale == 1.0 and args.tile == 0 else (None, None)
     if rank == 0:
         step_bytes = prm["step"]                       # `step` bytes read per window
         achieved = serial_windows * step_bytes / (launch_ms * 1e-3) / 1e9
@@ -428,6 +499,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "pass_with_peaks_ms": pass_with_peaks_ms,
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
@@ -462,7 +534,9 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": profiled_traffic(args.workload) if args.scale == 1.0 and args.tile == 0 else None,
+                "traffic": traffic,
+                "traffic_source": (f"{traffic_src}: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over "
+                                   f"this command (committed profile, not measured in this run)") if traffic_src else None,
                 "algorithmic_bytes": int(serial_windows * step_bytes),
                 "bytes_per_window": step_bytes,
                 "launch_ms": launch_ms,
@@ -500,6 +574,8 @@ def main():
                                             "sample": f"all {len(batches[0])} ctgs of the first batch, one ctg per "
                                                       f"worker thread, {T} threads on {os.cpu_count()} cpus"}
             out["parity_vs_oracle"] = ok
+        if world == 1 and not args.no_e2e:
+            out["end_to_end"] = end_to_end(eng, batches[0], prm)
     for p in plans:
         p.close()
     for ss in sets:

@@ -32,7 +32,7 @@ SW_ROW_DTYPE = np.dtype([("feature", np.uint32), ("type", np.int32), ("distance"
                          ("start", np.int32), ("end", np.int32), ("gc_content", np.float32),
                          ("gc_mean", np.float32), ("gc_stddev", np.float32), ("gc_cv", np.float32)])
 
-# name -> (restype, argtypes); exactly the entry points include/gams_gpu.h declares
+# name -> (restype, argtypes); exactly the entry points include/gams_gpu.h and include/gams_gpu_diag.h declare
 _VP = C.c_void_p
 _PP = C.POINTER(C.c_void_p)
 PROTOTYPES = {
@@ -51,6 +51,8 @@ PROTOTYPES = {
     "gams_seqset_create": (C.c_int, [_VP, C.c_uint32, _VP, _PP]),
     "gams_seqset_upload": (C.c_int, [_VP, _VP, C.c_uint32, _VP]),
     "gams_seqset_upload_all": (C.c_int, [_VP, _VP, _VP]),
+    "gams_seqset_layout": (C.c_int, [_VP, _VP, _VP, C.POINTER(C.c_uint64)]),
+    "gams_seqset_upload_image": (C.c_int, [_VP, _VP, _VP, C.c_uint64, C.c_uint64]),
     "gams_seqset_destroy": (None, [_VP, _VP]),
     "gams_wave_plan_create": (C.c_int, [_VP, _VP, C.POINTER(WaveParams), C.c_uint32, _PP]),
     "gams_wave_plan_destroy": (None, [_VP, _VP]),
@@ -61,6 +63,8 @@ PROTOTYPES = {
     "gams_wave_plan_select": (C.c_int, [_VP, _VP, C.c_uint32]),
     "gams_wave_plan_set_lane": (C.c_int, [_VP, _VP, C.c_uint32]),
     "gams_wave_plan_set_taper": (C.c_int, [_VP, _VP, C.c_int]),
+    "gams_wave_plan_set_taper_shape": (C.c_int, [_VP, _VP, C.c_int, C.c_int]),
+    "gams_wave_plan_set_queue_threads": (C.c_int, [_VP, _VP, C.c_uint32]),
     "gams_wave_plan_kernel_name": (C.c_int, [_VP, _VP, C.c_char_p, C.c_size_t]),
     "gams_wave_plan_set_pipelined": (C.c_int, [_VP, _VP, C.c_int]),
     "gams_wave_run": (C.c_int, [_VP, _VP]),
@@ -94,7 +98,7 @@ _lib = None
 
 
 def bind(path, strict=True):
-    """dlopen one build of the library and bind every prototype of include/gams_gpu.h.
+    """dlopen one build of the library and bind every prototype of include/gams_gpu.h + gams_gpu_diag.h.
     strict=False (tools/ab.py comparing against an older build) skips entry points it lacks."""
     lib = C.CDLL(path)
     for name, (res, args) in PROTOTYPES.items():

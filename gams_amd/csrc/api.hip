@@ -12,12 +12,8 @@ extern "C" {
 int gams_gpu_create(int device, gams_gpu_t **out) {
     if (!out) return GAMS_EINVAL;
     *out = nullptr;
-    // Kernel arguments in device memory: a workgroup's first instruction is a scalar load of its
-    // arguments, and from host memory that round trip is paid by every workgroup of every launch
-    // (12-Mb pass 9.5 -> 7.8 us, 4 passes in flight 3.5e11 -> 4.3e11 windows/s).  Read by the HIP
-    // runtime when it initialises: effective if no HIP call has been made in this process yet; a
-    // host that initialises HIP earlier exports it itself.  Never overrides the user.
-    setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
+    // (Kernel arguments in device memory -- HIP_FORCE_DEV_KERNARG=1 -- are the HOST's to ask for, before
+    // its first HIP call: the library does not touch the process environment.  INTEGRATION.md.)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return GAMS_ENODEV;
     if (device < 0 || device >= n) return GAMS_ENODEV;
@@ -374,6 +370,39 @@ int gams_seqset_upload_all(gams_gpu_t *h, gams_seqset_t *s, const uint8_t *const
     }
     GAMS_HIP(h, hipEventRecord(h->copy2_ev, second));
     GAMS_HIP(h, hipStreamWaitEvent(h->copy, h->copy2_ev, 0));
+    GAMS_HIP(h, hipEventRecord(s->uploaded, h->copy));
+    s->dirty = true;
+    ++s->upload_gen;
+    return GAMS_OK;
+}
+
+int gams_seqset_layout(gams_gpu_t *h, const gams_seqset_t *s, uint64_t *offsets, uint64_t *bytes) {
+    if (!s) return gams_fail(h, GAMS_EINVAL, "seqset_layout: null seqset");
+    if (offsets)
+        for (uint32_t i = 0; i < s->n_ctg; ++i) offsets[i] = s->off[i];
+    if (bytes) *bytes = s->bytes;
+    return GAMS_OK;
+}
+
+int gams_seqset_upload_image(gams_gpu_t *h, gams_seqset_t *s, const uint8_t *image, uint64_t lo, uint64_t hi) {
+    if (!h || !s || !image) return gams_fail(h, GAMS_EINVAL, "seqset_upload_image: null argument");
+    if (lo > hi || hi > s->bytes) return gams_fail(h, GAMS_EINVAL, "seqset_upload_image: range outside the seqset");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    if (lo == hi) return GAMS_OK;
+    if (s->gcindex) {
+        GAMS_HIP(h, hipStreamSynchronize(h->compute));
+        gams_seqset_gcindex_free(s);  // the bytes it indexed are about to change
+    }
+    if (!s->uploaded) GAMS_HIP(h, hipEventCreateWithFlags(&s->uploaded, hipEventDisableTiming));
+    // passes queued earlier on any stream of the handle may still be reading these bytes; once per
+    // generation of readers is enough, so only the first range of a burst pays the four event pairs
+    const uint64_t epoch = h->reader_epoch.load(std::memory_order_relaxed);
+    if (s->ordered_epoch != epoch) {
+        int rc = gams_order_after_readers(h, h->copy);
+        if (rc != GAMS_OK) return rc;
+        s->ordered_epoch = epoch;
+    }
+    GAMS_HIP(h, hipMemcpyAsync(s->d_seq + lo, image + lo, hi - lo, hipMemcpyHostToDevice, h->copy));
     GAMS_HIP(h, hipEventRecord(s->uploaded, h->copy));
     s->dirty = true;
     ++s->upload_gen;

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -12,6 +13,7 @@
 #include <vector>
 
 #include "../../include/gams_gpu.h"
+#include "../../include/gams_gpu_diag.h"
 
 struct gams_gpu {
     int device = 0;
@@ -54,6 +56,9 @@ struct gams_gpu {
     std::vector<Block> host_blocks;   // page-locked blocks handed out by gams_gpu_host_alloc (their pooled sizes)
     // hipFuncAttributeMaxDynamicSharedMemorySize belongs to the kernel FUNCTION (per device), not to a plan:
     // the largest value any launch on this handle has asked for, per function; only ever raised (gams_lds_attr)
+    // counts the launches that read a seqset (any stream of the handle): gams_seqset_upload_image queues the
+    // copy stream behind the handle's streams only when a reader was launched since it last did so
+    std::atomic<uint64_t> reader_epoch{1};
     std::unordered_map<const void *, size_t> lds_attr;
     std::mutex lds_mu;
 };
@@ -106,6 +111,7 @@ struct gams_seqset {
     hipEvent_t uploaded = nullptr;    // recorded on the copy stream after the last upload; kernels wait on it
     bool dirty = false;               // an upload happened since the last wait was queued (compute stream)
     uint64_t upload_gen = 0;          // counts uploads; streams other than `compute` compare it with what they saw
+    uint64_t ordered_epoch = 0;       // gams_gpu::reader_epoch when an upload last queued itself behind the readers
     gams_gcindex *gcindex = nullptr;  // built lazily by gams_gpu_sw, dropped by every upload
 };
 

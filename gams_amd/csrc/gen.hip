@@ -82,29 +82,33 @@ extern "C" int gams_gpu_valid_spans(gams_gpu_t *h, const uint8_t *seq, uint64_t 
     if (len == 0 || len > 0x7fffffffull) return gams_fail(h, GAMS_EINVAL, "valid_spans: length must be 1..2^31-1");
     GAMS_HIP(h, hipSetDevice(h->device));
     const uint64_t n_chunks = (len + 15) / 16;
-    uint8_t *d_seq = nullptr;
-    unsigned long long *d_flips = nullptr, *d_n = nullptr;
+    // device buffers from the handle's pool (one chromosome after another reuses them): the sequence, and
+    // one block holding the flip counter (first 256 B) and the flip list behind it
+    uint8_t *d_seq = nullptr, *d_blk = nullptr;
+    size_t seq_cap = 0, blk_cap = 0;
     uint64_t fcap = 1u << 16;
     auto cleanup = [&]() {
-        (void)hipFree(d_seq);
-        (void)hipFree(d_flips);
-        (void)hipFree(d_n);
+        gams_pool_free(h, false, d_seq, seq_cap);
+        gams_pool_free(h, false, d_blk, blk_cap);
+        d_seq = d_blk = nullptr;
     };
 #define G_HIP(call)                                                                            \
     do {                                                                                       \
         hipError_t e_ = (call);                                                                \
         if (e_ != hipSuccess) {                                                                \
+            (void)hipStreamSynchronize(h->compute); /* nothing may still use the blocks */     \
             cleanup();                                                                         \
             return gams_fail(h, GAMS_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
         }                                                                                      \
     } while (0)
-    G_HIP(hipMalloc(&d_seq, n_chunks * 16 + 16));
+    G_HIP(gams_pool_alloc(h, false, n_chunks * 16 + 16, reinterpret_cast<void **>(&d_seq), &seq_cap));
     G_HIP(hipMemsetAsync(d_seq + (n_chunks - 1) * 16, 0, 32, h->compute));
     G_HIP(hipMemcpyAsync(d_seq, seq, len, hipMemcpyHostToDevice, h->compute));
-    G_HIP(hipMalloc(&d_n, sizeof(unsigned long long)));
     std::vector<unsigned long long> flips;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        G_HIP(hipMalloc(&d_flips, fcap * sizeof(unsigned long long)));
+        G_HIP(gams_pool_alloc(h, false, 256 + fcap * sizeof(unsigned long long), reinterpret_cast<void **>(&d_blk), &blk_cap));
+        unsigned long long *const d_n = reinterpret_cast<unsigned long long *>(d_blk);
+        unsigned long long *const d_flips = reinterpret_cast<unsigned long long *>(d_blk + 256);
         G_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), h->compute));
         G_HIP(hipEventRecord(h->k0, h->compute));
         hipLaunchKernelGGL(gen_scan_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, h->compute, d_seq,
@@ -112,13 +116,14 @@ extern "C" int gams_gpu_valid_spans(gams_gpu_t *h, const uint8_t *seq, uint64_t 
         G_HIP(hipGetLastError());
         G_HIP(hipEventRecord(h->k1, h->compute));
         h->k_valid = true;
-    h->kq_used = 0;
-        unsigned long long nf = 0;
-        G_HIP(hipMemcpyAsync(&nf, d_n, sizeof nf, hipMemcpyDeviceToHost, h->compute));
+        h->kq_used = 0;
+        // the counter comes back through the handle's page-locked scratch word
+        G_HIP(hipMemcpyAsync(h->pin_scratch, d_n, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->compute));
         G_HIP(hipStreamSynchronize(h->compute));
+        const unsigned long long nf = h->pin_scratch[0];
         if (nf > fcap) {                 // more flips than the list holds: grow once and rescan
-            (void)hipFree(d_flips);
-            d_flips = nullptr;
+            gams_pool_free(h, false, d_blk, blk_cap);
+            d_blk = nullptr;
             fcap = nf;
             continue;
         }

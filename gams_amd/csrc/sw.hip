@@ -317,6 +317,7 @@ __global__ __launch_bounds__(256) void range_gc_kernel(const SwArgs a0, const in
 // lazily built per seqset; owned by the seqset (freed in gams_seqset_destroy)
 int gams_seqset_gcindex(gams_gpu_t *h, gams_seqset_t *s) {
     if (s->gcindex) return GAMS_OK;
+    h->reader_epoch.fetch_add(1, std::memory_order_relaxed);   // the build reads the sequence bytes
     int wrc = gams_seqset_wait_uploads(h, s);
     if (wrc != GAMS_OK) return wrc;
     gams_gcindex *ix = new gams_gcindex();

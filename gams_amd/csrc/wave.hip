@@ -88,6 +88,8 @@ struct gams_wave_plan {
     uint32_t lane = 0;                          // way k runs on stream (lane + k) % kMaxWays (gams_wave_plan_set_lane)
     int taper_req = -1;                         // gams_wave_plan_set_taper: -1 auto, 0 off, 1 on
     bool taper = false;                         // the tile table ends in W = 8 and W = 4 tiles (wave_fast_taper_kernel)
+    int taper4_pct = 25, taper8_pct = 50;       // size of the two tails, % of a round of workgroup slots (gams_wave_plan_set_taper_shape)
+    uint32_t queue_threads = gams_gpu::kMaxWays;   // host threads gams_wave_run_n queues from (gams_wave_plan_set_queue_threads)
     uint32_t last_way = 0;                      // way of the most recent run
     uint32_t sel_age = 0;                       // readers look at the run `sel_age` before the most recent one
     hipEvent_t ready = nullptr;                 // recorded on the compute stream behind the const table
@@ -221,10 +223,9 @@ void wave_fill_tiles_tapered(gams_wave_plan_t *p, uint32_t slots) {
     const gams_wave_params_t &q = p->prm;
     const uint32_t tw12 = 256u * 12u - q.lag - 1u, tw8 = 256u * 8u - q.lag - 1u, tw4 = 256u * 4u - q.lag - 1u;
     const uint64_t T = p->total_windows;
-    // measurement knobs: % of a round of workgroup slots for the W = 4 / W = 8 tails (gpurun_out/r2_taper_sweep.log:
+    // % of a round of workgroup slots for the W = 4 / W = 8 tails (defaults from gpurun_out/r2_taper_sweep.log:
     // 384 Mb 71.6 us without tails, 70.0 at 50/50, 68.5 at 25/50, 70.9 at 100/100; the 120-Mb launch 28.4-28.7 for all)
-    const char *e4 = getenv("GAMS_TAPER4"), *e8 = getenv("GAMS_TAPER8");   // read per plan (tools/ab_plans.py)
-    const int k4 = e4 ? atoi(e4) : 25, k8 = e8 ? atoi(e8) : 50;
+    const int k4 = p->taper4_pct, k8 = p->taper8_pct;                       // gams_wave_plan_set_taper_shape (0..100)
     const uint64_t x4 = std::min<uint64_t>((uint64_t)slots * k4 / 100 * tw4, T * 8 / 100);
     const uint64_t y8 = std::min<uint64_t>((uint64_t)slots * k8 / 100 * tw8, T * 17 / 100);
     p->tiles.clear();
@@ -638,6 +639,7 @@ int gams_wave_plan_set_guard(gams_gpu_t *h, gams_wave_plan_t *p, float safety, i
 static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
     gams_wave_plan::Way &w = p->way[k];
     hipStream_t st = wave_stream(h, p, k);
+    h->reader_epoch.fetch_add(1, std::memory_order_relaxed);   // a reader of the seqset is about to be queued
     // inputs: the way's stream queues behind the uploads and the plan's const table (no host wait)
     if (st == h->compute) {
         int wrc = gams_seqset_wait_uploads(h, p->set);
@@ -894,12 +896,7 @@ int gams_wave_run_n(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t n) {
     // (K = 1000 passes at depth 4: 4.4 / 3.1 / 3.0 / 3.0 us per pass with 1 / 2 / 3 / 4 threads;
     // K = 200: 3.8 / 3.8 / 3.6 / 3.5).  The first round goes through gams_wave_run on the caller: it
     // applies the kernel attribute and the first-use stream waits.
-    static const uint32_t max_threads = [] {
-        const char *e = getenv("GAMS_QUEUE_THREADS");          // 1..4; measurement knob
-        const int v = e ? atoi(e) : gams_gpu::kMaxWays;          // default: one queueing thread per way
-        return (uint32_t)std::min(std::max(v, 1), gams_gpu::kMaxWays);
-    }();
-    const uint32_t shares = std::min(max_threads, p->depth);
+    const uint32_t shares = std::min(p->queue_threads, p->depth);   // default: one queueing thread per way
     const bool threaded = p->depth >= 3 && shares >= 2 && n >= 4 * p->depth;
     if (!threaded) {
         for (uint32_t i = 0; i < n; ++i) {
@@ -990,6 +987,33 @@ int gams_wave_plan_set_taper(gams_gpu_t *h, gams_wave_plan_t *p, int mode) {
     rc = wave_upload_geometry(h, p);
     if (rc == GAMS_OK) rc = wave_alloc_ways(h, p);
     return rc;
+}
+
+int gams_wave_plan_set_taper_shape(gams_gpu_t *h, gams_wave_plan_t *p, int pct4, int pct8) {
+    if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_plan_set_taper_shape: null argument");
+    if (pct4 < 0 || pct4 > 100 || pct8 < 0 || pct8 > 100)
+        return gams_fail(h, GAMS_EINVAL, "wave_plan_set_taper_shape: percentages must be 0..100");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    int rc = wave_sync_ways(h, p);
+    if (rc != GAMS_OK) return rc;
+    p->taper4_pct = pct4;
+    p->taper8_pct = pct8;
+    rc = wave_build_geometry(h, p, p->tw_req);
+    if (rc != GAMS_OK) return rc;
+    p->ran = false;
+    (void)hipFree(p->d_stamps);
+    p->d_stamps = nullptr;
+    rc = wave_upload_geometry(h, p);
+    if (rc == GAMS_OK) rc = wave_alloc_ways(h, p);
+    return rc;
+}
+
+int gams_wave_plan_set_queue_threads(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t n) {
+    if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_plan_set_queue_threads: null argument");
+    if (n < 1 || n > (uint32_t)gams_gpu::kMaxWays)
+        return gams_fail(h, GAMS_EINVAL, "wave_plan_set_queue_threads: 1..4");
+    p->queue_threads = n;
+    return GAMS_OK;
 }
 
 int gams_wave_plan_kernel_name(gams_gpu_t *h, gams_wave_plan_t *p, char *buf, size_t n) {

@@ -144,6 +144,27 @@ class WavePlan:
         """-1 auto (on for depth 1), 0 off (passes in flight), 1 on: the launch ends in smaller tiles"""
         self.eng.check(self.eng.lib.gams_wave_plan_set_taper(self.eng.h, self.p, mode))
 
+    def set_pipelined(self, on):
+        """an event behind every run; peaks()/dense() then wait for that run only (plans in flight on lanes)"""
+        self.eng.check(self.eng.lib.gams_wave_plan_set_pipelined(self.eng.h, self.p, int(on)))
+
+    def peaks_count(self):
+        """wait for the selected run, pack and fetch its peaks into the plan's page-locked buffer; -> how many
+        (the records stay in plan-owned memory: what a C host reads in place, no copy into numpy)"""
+        ptr, n = C.c_void_p(), C.c_uint64()
+        self.eng.check(self.eng.lib.gams_wave_peaks(self.eng.h, self.p, C.byref(ptr), C.byref(n)))
+        return int(n.value)
+
+    def set_taper_shape(self, pct4, pct8=None):
+        """size of the tapered launch's two tails in % of a round of workgroup slots (default 25 / 50)"""
+        if pct8 is None:                      # tools/ab_plans.py passes one integer: pct4 * 1000 + pct8
+            pct4, pct8 = divmod(int(pct4), 1000)
+        self.eng.check(self.eng.lib.gams_wave_plan_set_taper_shape(self.eng.h, self.p, pct4, pct8))
+
+    def set_queue_threads(self, n):
+        """host threads run_n queues a long batch of passes from (1..4)"""
+        self.eng.check(self.eng.lib.gams_wave_plan_set_queue_threads(self.eng.h, self.p, n))
+
     def kernel_name(self):
         """the kernel that does this plan's work, as rocprofv3 --kernel-trace names it (gams_wave_plan_kernel_name)"""
         buf = C.create_string_buffer(160)

@@ -34,6 +34,18 @@ def load():
     L.gams_host_wave.restype = C.c_void_p
     L.gams_host_wave.argtypes = [C.c_void_p, C.c_uint32, sp, sp, ip, ip, C.POINTER(C.c_void_p), C.c_int32,
                                  C.c_int32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_int]
+    dp = C.POINTER(C.c_double)
+    L.gams_host_wave_timed.restype = C.c_void_p
+    L.gams_host_wave_timed.argtypes = [C.c_void_p, C.c_uint32, sp, sp, ip, ip, C.POINTER(C.c_void_p), C.c_int32,
+                                       C.c_int32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_int, dp,
+                                       C.POINTER(C.c_uint64)]
+    L.gams_host_wave_gz.restype = C.c_void_p
+    L.gams_host_wave_gz.argtypes = [C.c_void_p, C.c_uint32, sp, sp, ip, ip, C.POINTER(C.c_void_p), C.c_void_p, C.c_int32,
+                                    C.c_int32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_int, dp,
+                                    C.POINTER(C.c_uint64)]
+    L.gams_host_decode_gz_many.restype = C.c_int
+    L.gams_host_decode_gz_many.argtypes = [C.c_uint32, C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p,
+                                           C.c_void_p, C.c_uint32]
     L.gams_host_wave_multi.restype = C.c_void_p
     L.gams_host_wave_multi.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, sp, sp, ip, ip,
                                        C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_uint32, C.c_float,
@@ -126,6 +138,71 @@ def wave(eng, ctgs, size=100, step=10, lag=100, threshold=3.0, influence=1.0, co
     seqs = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in bufs])
     return _take(load().gams_host_wave(eng.h, n, ids, chrs, st.ctypes.data, en.ctypes.data, seqs, size, step, lag,
                                        threshold, influence, coverage, int(is_signal)))
+
+
+STAGE_NAMES = ("inflate_upload_ms", "upload_ms", "plan_ms", "kernel_ms", "peaks_ms", "format_ms", "total_ms",
+               "inflate_threads", "peaks")
+
+
+def _take_bytes(p, n):
+    L = load()
+    if not p:
+        raise HostError(L.gams_host_last_code(), L.gams_host_last_error().decode(errors="replace"))
+    b = C.string_at(p, n.value)
+    L.gams_host_free(p)
+    return b
+
+
+def _stage_dict(st):
+    d = {k: float(v) for k, v in zip(STAGE_NAMES, st)}
+    d["inflate_threads"] = int(d["inflate_threads"])
+    d["peaks"] = int(d["peaks"])
+    return d
+
+
+def wave_timed(eng, ctgs, size=100, step=10, lag=100, threshold=3.0, influence=1.0, coverage=0.2, sync=False):
+    """`wave` from gunzipped host buffers -> (TSV bytes, stage clock dict of gams::WaveStages)."""
+    n, ids, chrs, st, en = _ctg_arrays(ctgs)
+    bufs = [np.ascontiguousarray(np.frombuffer(c["seq"], np.uint8) if not isinstance(c["seq"], np.ndarray)
+                                 else c["seq"]) for c in ctgs]
+    seqs = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in bufs])
+    stages = (C.c_double * 10)()
+    ln = C.c_uint64()
+    p = load().gams_host_wave_timed(eng.h, n, ids, chrs, st.ctypes.data, en.ctypes.data, seqs, size, step, lag,
+                                    threshold, influence, coverage, int(sync), stages, C.byref(ln))
+    return _take_bytes(p, ln), _stage_dict(stages)
+
+
+def wave_gz(eng, ctgs, size=100, step=10, lag=100, threshold=3.0, influence=1.0, coverage=0.2, threads=0, sync=False):
+    """`wave` from the gzip'd `seq:` values (ctg dicts with id, chr_id, chr_start, chr_end, gz = bytes): `threads`
+    host threads inflate one ctg at a time each into a page-locked image of the device buffer (0: 16)
+    -> (TSV bytes, stage clock dict)."""
+    n, ids, chrs, st, en = _ctg_arrays(ctgs)
+    bufs = [np.frombuffer(c["gz"], np.uint8) for c in ctgs]
+    blobs = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in bufs])
+    lens = np.array([b.size for b in bufs], np.uint64)
+    stages = (C.c_double * 10)()
+    ln = C.c_uint64()
+    p = load().gams_host_wave_gz(eng.h, n, ids, chrs, st.ctypes.data, en.ctypes.data, blobs, lens.ctypes.data, size, step,
+                                 lag, threshold, influence, coverage, threads, int(sync), stages, C.byref(ln))
+    return _take_bytes(p, ln), _stage_dict(stages)
+
+
+def decode_gz_many(blobs, sizes, threads=0):
+    """decode_gz of a batch of `seq:` values on `threads` host threads (0: 16); sizes[i] = room for value i
+    -> list of uint8 arrays"""
+    L = load()
+    n = len(blobs)
+    src = [np.frombuffer(b, np.uint8) for b in blobs]
+    dst = [np.empty(max(int(s), 1), np.uint8) for s in sizes]
+    sp_ = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in src])
+    dp_ = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in dst])
+    sl = np.array([b.size for b in src], np.uint64)
+    cap = np.array([int(s) for s in sizes], np.uint64)
+    got = np.zeros(max(n, 1), np.uint64)
+    if L.gams_host_decode_gz_many(n, sp_, sl.ctypes.data, dp_, cap.ctypes.data, got.ctypes.data, threads) != 0:
+        raise HostError(L.gams_host_last_code(), L.gams_host_last_error().decode(errors="replace"))
+    return [d[:int(g)] for d, g in zip(dst, got)]
 
 
 def wave_multi(engines, ctgs, size=100, step=10, lag=100, threshold=3.0, influence=1.0, coverage=0.2,

@@ -15,7 +15,9 @@
 #include <queue>
 #include <thread>
 
+#include <dlfcn.h>
 #include <zlib.h>
+#include <chrono>
 
 namespace gams {
 
@@ -267,28 +269,126 @@ void parallel_for(uint32_t n, F fn) {
     if (err) std::rethrow_exception(err);
 }
 
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 struct WaveJob {
     gams_gpu_t *h;
     std::vector<Ctg> ctgs;
     WaveArgs a;
     SeqSetGuard sg;
     PlanGuard pg;
+    uint8_t *image = nullptr;      // start_gz: page-locked image of the seqset the workers inflate into
+    WaveStages *st = nullptr;      // optional stage clock (wave_proc_ctgs*, see gams_host.hpp)
+    double t_mark = 0;
     WaveJob(gams_gpu_t *h_, std::vector<Ctg> c, const WaveArgs &a_) : h(h_), ctgs(std::move(c)), a(a_), sg{h_}, pg{h_} {}
+    ~WaveJob() {
+        if (image) {
+            (void)gams_gpu_sync(h);            // a DMA may still be reading it
+            gams_gpu_host_free(h, image);
+        }
+    }
     void start(const std::vector<const uint8_t *> &seqs);
+    void start_gz(const std::vector<const uint8_t *> &blobs, const std::vector<uint64_t> &blob_len, unsigned threads);
     std::vector<std::string> finish();
+    // stage clock: with st->sync the device is drained first, so the interval belongs to the stage just queued
+    void mark(double WaveStages::*slot) {
+        if (!st) return;
+        if (st->sync) check(h, gams_gpu_sync(h));
+        const double t = now_ms();
+        st->*slot += t - t_mark;
+        t_mark = t;
+    }
+    void plan_and_run();
 };
+
+void WaveJob::plan_and_run() {
+    gams_wave_params_t prm{a.size, a.step, a.lag, a.threshold, a.influence};
+    check(h, gams_wave_plan_create(h, sg.s, &prm, a.signal ? GAMS_WAVE_DENSE : GAMS_WAVE_PEAKS, &pg.p));
+    check(h, gams_wave_plan_set_pipelined(h, pg.p, 1));   // finish() waits for this job, not the stream
+    mark(&WaveStages::plan_ms);
+    check(h, gams_wave_run(h, pg.p));
+    mark(&WaveStages::kernel_ms);
+}
 
 void WaveJob::start(const std::vector<const uint8_t *> &seqs) {
     const uint32_t n = (uint32_t)ctgs.size();
     if (n == 0) return;
+    t_mark = now_ms();
     std::vector<uint32_t> lens(n);
     for (uint32_t c = 0; c < n; ++c) lens[c] = (uint32_t)(ctgs[c].chr_end - ctgs[c].chr_start + 1);
     check(h, gams_seqset_create(h, n, lens.data(), &sg.s));
     check(h, gams_seqset_upload_all(h, sg.s, seqs.data()));
-    gams_wave_params_t prm{a.size, a.step, a.lag, a.threshold, a.influence};
-    check(h, gams_wave_plan_create(h, sg.s, &prm, a.signal ? GAMS_WAVE_DENSE : GAMS_WAVE_PEAKS, &pg.p));
-    check(h, gams_wave_plan_set_pipelined(h, pg.p, 1));   // finish() waits for this job, not the stream
-    check(h, gams_wave_run(h, pg.p));
+    mark(&WaveStages::upload_ms);
+    plan_and_run();
+}
+
+// The `seq:` values as the store holds them (gzip members, redis.rs:149-161): `threads` workers take the
+// ctgs in order -- one ctg per worker at a time, like the reference's --parallel workers (wave.rs:288-299
+// call get_seq -> decode_gz inside the worker) -- and inflate each one straight into a page-locked image
+// of the device buffer; the calling thread follows them and hands every finished stretch of >= 8 MiB to
+// the DMA engine (gams_seqset_upload_image): no staging copy, and the upload hides behind the inflate.
+void WaveJob::start_gz(const std::vector<const uint8_t *> &blobs, const std::vector<uint64_t> &blob_len,
+                       unsigned threads) {
+    const uint32_t n = (uint32_t)ctgs.size();
+    if (n == 0) return;
+    t_mark = now_ms();
+    std::vector<uint32_t> lens(n);
+    for (uint32_t c = 0; c < n; ++c) lens[c] = (uint32_t)(ctgs[c].chr_end - ctgs[c].chr_start + 1);
+    check(h, gams_seqset_create(h, n, lens.data(), &sg.s));
+    std::vector<uint64_t> off(n);
+    uint64_t bytes = 0;
+    check(h, gams_seqset_layout(h, sg.s, off.data(), &bytes));
+    void *blk = nullptr;
+    check(h, gams_gpu_host_alloc(h, bytes, &blk));
+    image = static_cast<uint8_t *>(blk);
+    const unsigned T = std::max(1u, std::min(threads ? threads : 16u, n));
+    if (st) st->threads = T;
+    std::vector<std::atomic<uint8_t>> done(n);
+    for (auto &d : done) d.store(0, std::memory_order_relaxed);
+    std::atomic<uint32_t> next{0};
+    std::atomic<bool> failed{false};
+    std::exception_ptr err;
+    std::mutex mu;
+    auto work = [&] {
+        try {
+            for (uint32_t i = next.fetch_add(1); i < n && !failed.load(); i = next.fetch_add(1)) {
+                const size_t got = decode_gz_into(blobs[i], (size_t)blob_len[i], image + off[i], lens[i]);
+                if (got != lens[i])
+                    throw Error(GAMS_EINVAL, "seq:" + ctgs[i].id + " inflates to " + std::to_string(got) +
+                                                 " bases, the ctg record says " + std::to_string(lens[i]));
+                // the alignment gap behind the ctg (never counted; kept defined)
+                const uint64_t end = off[i] + lens[i], stop = i + 1 < n ? off[i + 1] : end;
+                if (stop > end) std::memset(image + end, 0, stop - end);
+                done[i].store(1, std::memory_order_release);
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!err) err = std::current_exception();
+            failed.store(true);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < T; ++t) pool.emplace_back(work);
+    // follow the workers: ctgs are taken in order, so they also finish roughly in order
+    constexpr uint64_t kPiece = 8ull << 20;
+    uint64_t lo = 0;
+    int rc = GAMS_OK;
+    for (uint32_t i = 0; i < n && rc == GAMS_OK; ++i) {
+        while (!done[i].load(std::memory_order_acquire) && !failed.load()) std::this_thread::yield();
+        if (failed.load()) break;
+        const uint64_t hi = i + 1 < n ? off[i + 1] : off[i] + lens[i];
+        if (hi - lo >= kPiece || i + 1 == n) {
+            rc = gams_seqset_upload_image(h, sg.s, image, lo, hi);
+            lo = hi;
+        }
+    }
+    for (auto &th : pool) th.join();
+    if (err) std::rethrow_exception(err);
+    check(h, rc);
+    mark(&WaveStages::inflate_upload_ms);
+    plan_and_run();
 }
 
 std::vector<std::string> WaveJob::finish() {
@@ -329,6 +429,8 @@ std::vector<std::string> WaveJob::finish() {
     const gams_peak_t *pk = nullptr;
     uint64_t np = 0;
     check(h, gams_wave_peaks(h, pg.p, &pk, &np));
+    mark(&WaveStages::peaks_ms);
+    if (st) st->peaks = np;
     // peaks arrive ordered by (ctg, window): slice per ctg, then merge + format the ctgs on a few
     // host threads (the rows of one ctg depend on nothing else)
     std::vector<uint64_t> first(n + 1, np);
@@ -382,17 +484,36 @@ std::vector<std::string> WaveJob::finish() {
             o += '\n';
         }
     });
+    mark(&WaveStages::format_ms);
     return out;
 }
 
 }  // namespace
 
 std::vector<std::string> wave_proc_ctgs(gams_gpu_t *h, const std::vector<Ctg> &ctgs,
-                                        const std::vector<const uint8_t *> &seqs, const WaveArgs &a) {
+                                        const std::vector<const uint8_t *> &seqs, const WaveArgs &a, WaveStages *stages) {
     if (ctgs.size() != seqs.size()) throw Error(GAMS_EINVAL, "wave_proc_ctgs: ctgs/seqs size mismatch");
+    const double t0 = now_ms();
     WaveJob job(h, ctgs, a);
+    job.st = stages;
     job.start(seqs);
-    return job.finish();
+    std::vector<std::string> out = job.finish();
+    if (stages) stages->total_ms += now_ms() - t0;
+    return out;
+}
+
+std::vector<std::string> wave_proc_ctgs_gz(gams_gpu_t *h, const std::vector<Ctg> &ctgs,
+                                           const std::vector<const uint8_t *> &blobs, const std::vector<uint64_t> &blob_len,
+                                           const WaveArgs &a, unsigned threads, WaveStages *stages) {
+    if (ctgs.size() != blobs.size() || ctgs.size() != blob_len.size())
+        throw Error(GAMS_EINVAL, "wave_proc_ctgs_gz: ctgs/blobs size mismatch");
+    const double t0 = now_ms();
+    WaveJob job(h, ctgs, a);
+    job.st = stages;
+    job.start_gz(blobs, blob_len, threads);
+    std::vector<std::string> out = job.finish();
+    if (stages) stages->total_ms += now_ms() - t0;
+    return out;
 }
 
 std::string wave_proc_ctg(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq, const WaveArgs &a) {
@@ -1287,25 +1408,147 @@ std::vector<Record> feature_records(Locator &loc, const std::vector<std::string>
     return out;
 }
 
-std::string decode_gz(const uint8_t *bytes, size_t n) {
+namespace {
+// libdeflate (the runtime library ships with the image: libdeflate.so.0, no headers) inflates DNA text about
+// three times as fast as zlib; bound by hand to its stable C API, zlib when it is absent.
+struct LibDeflate {
+    void *(*alloc)() = nullptr;
+    int (*gunzip)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    void (*release)(void *) = nullptr;
+    LibDeflate() {
+        if (void *so = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL)) {
+            alloc = reinterpret_cast<void *(*)()>(dlsym(so, "libdeflate_alloc_decompressor"));
+            gunzip = reinterpret_cast<int (*)(void *, const void *, size_t, void *, size_t, size_t *)>(
+                dlsym(so, "libdeflate_gzip_decompress"));
+            release = reinterpret_cast<void (*)(void *)>(dlsym(so, "libdeflate_free_decompressor"));
+            if (!alloc || !gunzip || !release) alloc = nullptr;
+        }
+    }
+    bool ok() const { return alloc != nullptr; }
+};
+const LibDeflate &libdeflate() {
+    static const LibDeflate L;
+    return L;
+}
+struct Decompressor {   // one per thread, reused
+    void *d = nullptr;
+    ~Decompressor() {
+        if (d) libdeflate().release(d);
+    }
+};
+
+size_t zlib_gunzip_into(const uint8_t *bytes, size_t n, uint8_t *dst, size_t cap, bool *overflow) {
     z_stream zs{};
     if (inflateInit2(&zs, 15 + 16) != Z_OK) throw Error(GAMS_EINVAL, "decode_gz: inflateInit2 failed");
     zs.next_in = const_cast<Bytef *>(bytes);
     zs.avail_in = (uInt)n;
-    std::string out;
-    char buf[1 << 16];
+    size_t at = 0;
     int rc;
     do {
-        zs.next_out = reinterpret_cast<Bytef *>(buf);
-        zs.avail_out = sizeof buf;
+        zs.next_out = dst + at;
+        zs.avail_out = (uInt)std::min<size_t>(cap - at, 1u << 30);
+        const size_t room = zs.avail_out;
         rc = inflate(&zs, Z_NO_FLUSH);
+        at += room - zs.avail_out;
         if (rc != Z_OK && rc != Z_STREAM_END) {
             inflateEnd(&zs);
             throw Error(GAMS_EINVAL, "decode_gz: corrupt gzip member");
         }
-        out.append(buf, sizeof buf - zs.avail_out);
+        if (rc == Z_OK && at == cap) {          // output full before the member ended
+            inflateEnd(&zs);
+            *overflow = true;
+            return at;
+        }
     } while (rc != Z_STREAM_END);
     inflateEnd(&zs);
+    return at;
+}
+}  // namespace
+
+// The first gzip member of `bytes` (flate2's GzDecoder reads one member, redis.rs:156-161) inflated into
+// dst[0, cap); returns the bases written.  A member longer than cap is an error.
+size_t decode_gz_into(const uint8_t *bytes, size_t n, uint8_t *dst, size_t cap) {
+    if (n < 18) throw Error(GAMS_EINVAL, "decode_gz: corrupt gzip member");
+    if (libdeflate().ok()) {
+        static thread_local Decompressor dc;
+        if (!dc.d) dc.d = libdeflate().alloc();
+        if (dc.d) {
+            size_t got = 0;
+            const int rc = libdeflate().gunzip(dc.d, bytes, n, dst, cap, &got);
+            if (rc == 0) return got;
+            if (rc == 3) throw Error(GAMS_EINVAL, "decode_gz: the member inflates to more than " + std::to_string(cap) + " bytes");
+            throw Error(GAMS_EINVAL, "decode_gz: corrupt gzip member");
+        }
+    }
+    bool overflow = false;
+    const size_t got = zlib_gunzip_into(bytes, n, dst, cap, &overflow);
+    if (overflow) throw Error(GAMS_EINVAL, "decode_gz: the member inflates to more than " + std::to_string(cap) + " bytes");
+    return got;
+}
+
+std::string decode_gz(const uint8_t *bytes, size_t n) {
+    if (n < 18) throw Error(GAMS_EINVAL, "decode_gz: corrupt gzip member");
+    // ISIZE (RFC 1952: uncompressed size mod 2^32 in the last four bytes) sizes the output in one piece for a
+    // single-member value, which is what the reference stores; anything else grows the buffer
+    uint32_t isize;
+    std::memcpy(&isize, bytes + n - 4, 4);
+    std::string out;
+    // (deflate cannot expand beyond 1032:1, so a trailer claiming more is not believed)
+    size_t cap = std::max<size_t>(std::min<uint64_t>(isize, (uint64_t)n * 1032u + 64u), 64);
+    for (int attempt = 0; attempt < 40; ++attempt) {
+        out.resize(cap);
+        if (libdeflate().ok()) {
+            static thread_local Decompressor dc;
+            if (!dc.d) dc.d = libdeflate().alloc();
+            if (dc.d) {
+                size_t got = 0;
+                const int rc = libdeflate().gunzip(dc.d, bytes, n, &out[0], cap, &got);
+                if (rc == 0) {
+                    out.resize(got);
+                    return out;
+                }
+                if (rc != 3) throw Error(GAMS_EINVAL, "decode_gz: corrupt gzip member");
+                cap *= 2;
+                continue;
+            }
+        }
+        bool overflow = false;
+        const size_t got = zlib_gunzip_into(bytes, n, reinterpret_cast<uint8_t *>(&out[0]), cap, &overflow);
+        if (!overflow) {
+            out.resize(got);
+            return out;
+        }
+        cap *= 2;
+    }
+    throw Error(GAMS_EINVAL, "decode_gz: output too large");
+}
+
+// get_seq + decode_gz for a batch of values on `threads` host threads, one ctg per worker at a time
+// (redis.rs:142-161 inside the workers of wave.rs:288-299)
+std::vector<std::string> decode_gz_many(const std::vector<const uint8_t *> &blobs, const std::vector<uint64_t> &blob_len,
+                                        unsigned threads) {
+    if (blobs.size() != blob_len.size()) throw Error(GAMS_EINVAL, "decode_gz_many: blobs/lengths size mismatch");
+    const uint32_t n = (uint32_t)blobs.size();
+    std::vector<std::string> out(n);
+    const unsigned T = std::max(1u, std::min(threads ? threads : 16u, std::max(n, 1u)));
+    std::atomic<uint32_t> next{0};
+    std::exception_ptr err;
+    std::mutex mu;
+    auto work = [&] {
+        try {
+            for (uint32_t i = next.fetch_add(1); i < n; i = next.fetch_add(1))
+                out[i] = decode_gz(blobs[i], (size_t)blob_len[i]);
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!err) err = std::current_exception();
+            next.store(n);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < T; ++t) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+    if (err) std::rethrow_exception(err);
     return out;
 }
 
@@ -1333,10 +1576,15 @@ std::string encode_gz(const uint8_t *bytes, size_t n) {
 // ---------------------------------------------------------------------------
 std::vector<Ctg> gen_ctgs(gams_gpu_t *h, const std::string &chr_id, const uint8_t *seq, uint64_t len,
                           const GenArgs &a) {
+    // one scan of the chromosome; a second only if it has more valid regions than a generous first guess
     uint64_t n = 0;
-    check(h, gams_gpu_valid_spans(h, seq, len, a.fill, a.min, nullptr, nullptr, 0, &n));
-    std::vector<int32_t> lo(n ? n : 1), hi(n ? n : 1);
-    check(h, gams_gpu_valid_spans(h, seq, len, a.fill, a.min, lo.data(), hi.data(), n, &n));
+    std::vector<int32_t> lo(4096), hi(4096);
+    check(h, gams_gpu_valid_spans(h, seq, len, a.fill, a.min, lo.data(), hi.data(), lo.size(), &n));
+    if (n > lo.size()) {
+        lo.resize(n);
+        hi.resize(n);
+        check(h, gams_gpu_valid_spans(h, seq, len, a.fill, a.min, lo.data(), hi.data(), n, &n));
+    }
     std::vector<Ctg> out;
     int32_t serial = 0;
     for (uint64_t i = 0; i < n; ++i) {                                 // gen.rs:108-126

@@ -68,9 +68,31 @@ public:
     Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
 };
 
+// Where the time of one wave_proc_ctgs* call went, in ms (added to, so a caller may sum several calls).  With
+// `sync` set the device is drained at every stage boundary, so each interval belongs to the stage just
+// queued (a breakdown run: slower than the pipelined call, whose only host waits are in peaks); without it
+// the slots hold host time between checkpoints and only total_ms means much.
+struct WaveStages {
+    bool sync = false;
+    unsigned threads = 0;          // inflate workers used (gz form)
+    uint64_t peaks = 0;            // signalled windows fetched
+    double inflate_upload_ms = 0;  // gz form: seq: values -> bases in a page-locked image -> HBM (overlapped)
+    double upload_ms = 0;          // buffer form: host buffers -> HBM (gams_seqset_upload_all)
+    double plan_ms = 0, kernel_ms = 0, peaks_ms = 0, format_ms = 0, total_ms = 0;
+};
+
 // wave.rs:121-215 for a batch of ctgs in ONE device pass; returns one String per ctg
 std::vector<std::string> wave_proc_ctgs(gams_gpu_t *h, const std::vector<Ctg> &ctgs,
-                                        const std::vector<const uint8_t *> &seqs, const WaveArgs &a);
+                                        const std::vector<const uint8_t *> &seqs, const WaveArgs &a,
+                                        WaveStages *stages = nullptr);
+// The same from the `seq:{ctg}` values as the store holds them (gzip members, redis.rs:149-161):
+// blobs[i] / blob_len[i] = the value of ctgs[i], which must inflate to exactly ctgs[i].length bases.
+// `threads` workers inflate one ctg at a time each (the reference gunzips inside its --parallel workers,
+// wave.rs:288-299 -> redis.rs:142-161) straight into a page-locked image of the device buffer, and the
+// finished stretches go to the DMA engine while the rest still inflates.  threads == 0: 16.
+std::vector<std::string> wave_proc_ctgs_gz(gams_gpu_t *h, const std::vector<Ctg> &ctgs,
+                                           const std::vector<const uint8_t *> &blobs, const std::vector<uint64_t> &blob_len,
+                                           const WaveArgs &a, unsigned threads = 0, WaveStages *stages = nullptr);
 std::string wave_proc_ctg(gams_gpu_t *h, const Ctg &ctg, const uint8_t *seq, const WaveArgs &a);
 // The multi-GPU form: ctgs are split over the handles by longest-
 // processing-time-first on their window counts, one host thread per handle, each thread walks
@@ -142,6 +164,11 @@ class Locator;
 
 // src/libs/redis.rs:149-161: the `seq:` values are gzip members (flate2, Compression::fast)
 std::string decode_gz(const uint8_t *bytes, size_t n);
+// ... into caller memory (at most cap bytes; more is an error); returns the bytes written
+size_t decode_gz_into(const uint8_t *bytes, size_t n, uint8_t *dst, size_t cap);
+// a batch of values on `threads` host threads (0: 16), one value per worker at a time
+std::vector<std::string> decode_gz_many(const std::vector<const uint8_t *> &blobs, const std::vector<uint64_t> &blob_len,
+                                        unsigned threads = 0);
 std::string encode_gz(const uint8_t *bytes, size_t n);
 
 // src/libs/utils.rs:39-67 read_range: locate every valid range and bucket it by ctg, INCLUDING

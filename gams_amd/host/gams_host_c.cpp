@@ -108,6 +108,106 @@ char *gams_host_wave(gams_gpu_t *h, uint32_t n, const char *const *ids, const ch
     });
 }
 
+namespace {
+// stages[0..9] = inflate_upload, upload, plan, kernel, peaks, format, total ms, threads, peaks fetched, reserved
+void put_stages(const gams::WaveStages &st, double *stages) {
+    if (!stages) return;
+    stages[0] = st.inflate_upload_ms;
+    stages[1] = st.upload_ms;
+    stages[2] = st.plan_ms;
+    stages[3] = st.kernel_ms;
+    stages[4] = st.peaks_ms;
+    stages[5] = st.format_ms;
+    stages[6] = st.total_ms;
+    stages[7] = (double)st.threads;
+    stages[8] = (double)st.peaks;
+    stages[9] = 0;
+}
+}  // namespace
+
+// gams_host_wave with the stage clock of gams::WaveStages (sync != 0: the device is drained at every stage
+// boundary); *out_len receives the length of the text
+char *gams_host_wave_timed(gams_gpu_t *h, uint32_t n, const char *const *ids, const char *const *chrs,
+                           const int32_t *starts, const int32_t *ends, const uint8_t *const *seqs, int32_t size,
+                           int32_t step, uint32_t lag, float threshold, float influence, float coverage, int sync,
+                           double *stages, uint64_t *out_len) {
+    return guarded_bytes(out_len, [&] {
+        gams::WaveArgs a;
+        a.size = size;
+        a.step = step;
+        a.lag = lag;
+        a.threshold = threshold;
+        a.influence = influence;
+        a.coverage = coverage;
+        gams::WaveStages st;
+        st.sync = sync != 0;
+        std::vector<const uint8_t *> sp(seqs, seqs + n);
+        std::vector<std::string> rows = gams::wave_proc_ctgs(h, make_ctgs(n, ids, chrs, starts, ends), sp, a, &st);
+        put_stages(st, stages);
+        size_t total = 0;
+        for (auto &s : rows) total += s.size();
+        std::string out;
+        out.reserve(total);
+        for (auto &s : rows) out += s;
+        return out;
+    });
+}
+
+// the same from the gzip'd `seq:` values (gams::wave_proc_ctgs_gz): blobs[i] / blob_len[i] = value of ctg i
+char *gams_host_wave_gz(gams_gpu_t *h, uint32_t n, const char *const *ids, const char *const *chrs,
+                        const int32_t *starts, const int32_t *ends, const uint8_t *const *blobs,
+                        const uint64_t *blob_len, int32_t size, int32_t step, uint32_t lag, float threshold,
+                        float influence, float coverage, uint32_t threads, int sync, double *stages, uint64_t *out_len) {
+    return guarded_bytes(out_len, [&] {
+        gams::WaveArgs a;
+        a.size = size;
+        a.step = step;
+        a.lag = lag;
+        a.threshold = threshold;
+        a.influence = influence;
+        a.coverage = coverage;
+        gams::WaveStages st;
+        st.sync = sync != 0;
+        std::vector<const uint8_t *> bp(blobs, blobs + n);
+        std::vector<uint64_t> bl(blob_len, blob_len + n);
+        std::vector<std::string> rows =
+            gams::wave_proc_ctgs_gz(h, make_ctgs(n, ids, chrs, starts, ends), bp, bl, a, threads, &st);
+        put_stages(st, stages);
+        size_t total = 0;
+        for (auto &s : rows) total += s.size();
+        std::string out;
+        out.reserve(total);
+        for (auto &s : rows) out += s;
+        return out;
+    });
+}
+
+// decode_gz of n values on `threads` host threads into caller buffers: dst[i] has room for dst_cap[i] bytes,
+// got[i] receives the bytes written.  Returns 0, or -1 with the message in gams_host_last_error().
+int gams_host_decode_gz_many(uint32_t n, const uint8_t *const *blobs, const uint64_t *blob_len, uint8_t *const *dst,
+                             const uint64_t *dst_cap, uint64_t *got, uint32_t threads) {
+    try {
+        g_err.clear();
+        g_code = 0;
+        std::vector<const uint8_t *> bp(blobs, blobs + n);
+        std::vector<uint64_t> bl(blob_len, blob_len + n);
+        std::vector<std::string> out = gams::decode_gz_many(bp, bl, threads);
+        for (uint32_t i = 0; i < n; ++i) {
+            if (out[i].size() > dst_cap[i]) throw gams::Error(GAMS_EINVAL, "decode_gz_many: value " + std::to_string(i) + " does not fit");
+            std::memcpy(dst[i], out[i].data(), out[i].size());
+            got[i] = out[i].size();
+        }
+        return 0;
+    } catch (const gams::Error &e) {
+        g_err = e.what();
+        g_code = e.code;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        g_code = -1;
+    }
+    return -1;
+}
+
 // the same over several handles (one per device; tests pass two handles of one device)
 char *gams_host_wave_multi(gams_gpu_t *const *handles, uint32_t n_handles, uint32_t n, const char *const *ids,
                            const char *const *chrs, const int32_t *starts, const int32_t *ends,

@@ -20,6 +20,13 @@
  *   gams_gpu_locate           src/libs/utils.rs:7-22        (find_one_idx -> Lapper::find().next())
  *   gams_gpu_cover            src/cmd_gams/anno.rs:128-139  (IntSpan intersect cardinalities)
  *   gams_gpu_valid_spans      src/cmd_gams/gen.rs:86-104    (ambiguous-base scan, fill, excise)
+ *
+ * Measurement and tuning entries (event stopwatch, phase stamps, guard-band and tile knobs, kernel
+ * names) are NOT part of this surface: they live in gams_gpu_diag.h, which a host need not bind.
+ *
+ * Environment: the library neither reads nor writes the process environment.  Kernel arguments in
+ * device memory (HIP_FORCE_DEV_KERNARG=1, set by the host BEFORE its first HIP call) shorten every
+ * launch by the PCIe round trip of the argument fetch (12-Mb pass 9.5 -> 7.8 us); see INTEGRATION.md.
  */
 #ifndef GAMS_GPU_H
 #define GAMS_GPU_H
@@ -59,14 +66,6 @@ int gams_gpu_sync(gams_gpu_t *h);
  * blocks, a quarter of the HBM, 1 GiB pinned); this returns them to the driver now.
  * cached_bytes (may be NULL) receives what was held. */
 int gams_gpu_release_cached(gams_gpu_t *h, uint64_t *cached_bytes);
-/* HIP-event stopwatch on the handle's compute stream (the stream the kernels of this library
- * are launched on; plans of depth > 1 also use auxiliary streams, which stop() queues the
- * compute stream behind before it records the closing event).  stop() synchronises and returns ms. */
-int gams_gpu_timer_start(gams_gpu_t *h);
-int gams_gpu_timer_stop(gams_gpu_t *h, float *ms);
-/* Device time (HIP events around the kernel, excluding the host<->device copies) of the last
- * gams_gpu_sw / gams_gpu_count / gams_gpu_locate / gams_gpu_cover call on this handle. */
-int gams_gpu_last_kernel_ms(gams_gpu_t *h, float *ms);
 /* Page-locked host memory for query / result columns: gams_gpu_count, gams_gpu_locate and gams_gpu_cover
  * move their columns in chunks (copy in, search, copy out on three streams); from page-locked arrays the
  * three overlap and a call runs at the rate of the PCIe link.  Any host memory works. */
@@ -92,6 +91,18 @@ int gams_seqset_upload(gams_gpu_t *h, gams_seqset_t *s, uint32_t i,
  * the batch form of the per-ctg GET loop (wave.rs:134-136).  Several host threads fill pinned
  * staging buffers in the device layout, one DMA per 16 MiB; returns once everything is queued. */
 int gams_seqset_upload_all(gams_gpu_t *h, gams_seqset_t *s, const uint8_t *const *seqs);
+/* Where the library put the ctgs: offsets[i] (n_ctg entries, may be NULL) = byte offset of ctg i in the
+ * device buffer, *bytes (may be NULL) = the buffer's size in use.  A host that produces the bases itself
+ * -- gunzip of the `seq:` values, redis.rs:142-161 -- writes them at these offsets of a page-locked
+ * block of *bytes bytes (gams_gpu_host_alloc) and hands ranges of that image to
+ * gams_seqset_upload_image: no staging copy between the inflate and the DMA. */
+int gams_seqset_layout(gams_gpu_t *h, const gams_seqset_t *s, uint64_t *offsets, uint64_t *bytes);
+/* DMA bytes [lo, hi) of `image` (a host image of the device buffer, laid out as gams_seqset_layout says)
+ * to the same bytes of the device buffer, on the handle's copy stream; returns once queued.  The image must
+ * stay untouched until the next gams_gpu_sync / a reader of the seqset has finished.  Page-locked images
+ * (gams_gpu_host_alloc) go at the rate of the link; pageable ones work but stage through the driver.
+ * Bytes between ctgs (alignment gaps) are never counted: they may hold anything. */
+int gams_seqset_upload_image(gams_gpu_t *h, gams_seqset_t *s, const uint8_t *image, uint64_t lo, uint64_t hi);
 void gams_seqset_destroy(gams_gpu_t *h, gams_seqset_t *s);
 
 /* ---- wave (GC windows + smoothed z-score) ------------------------------- */
@@ -141,18 +152,6 @@ int gams_wave_plan_select(gams_gpu_t *h, gams_wave_plan_t *plan, uint32_t age);
  * overlap on the device exactly like the ways of one plan; the readers wait for their own plan only.
  * Call while the plan is idle (it waits for the plan's queued runs). */
 int gams_wave_plan_set_lane(gams_gpu_t *h, gams_wave_plan_t *plan, uint32_t lane);
-/* Tapered launches.  A launch of the headline parameters (size 100, step 10, lag 100) over at least a
- * round and a half of workgroups ends in smaller tiles (the ctgs holding the last 17 % / 8 % of the
- * windows are cut into tiles of 2/3 and 1/3 the size), so that its last workgroups are short-lived and
- * the chip drains in ~3 instead of ~10 us; the small tiles cost 3-4 % more work.  mode -1 (default):
- * on for plans of depth 1; 0: off -- what a host wants that keeps several passes in flight (plans on
- * lanes, or depth > 1): their tails overlap anyway; 1: on.  Results are identical either way. */
-int gams_wave_plan_set_taper(gams_gpu_t *h, gams_wave_plan_t *plan, int mode);
-/* Name of the kernel that does the plan's work, spelled as rocprofv3 --kernel-trace prints the
- * instantiation (without the namespace), e.g. "wave_fast_taper_kernel<100, 10, 100, true>": lets a
- * benchmark line name the row of the profile its launch duration must agree with.  Follows the plan's
- * current settings (set_tile / set_taper / the seqset's size).  NUL-terminated, truncated to n. */
-int gams_wave_plan_kernel_name(gams_gpu_t *h, gams_wave_plan_t *plan, char *buf, size_t n);
 /* Pipelined plans record an event behind every run, and gams_wave_peaks / gams_wave_dense wait
  * for that run only (so a host can keep several plans in flight on one handle: upload of batch
  * k+1 and its kernel overlap the readback and formatting of batch k).  Off by default: the
@@ -165,25 +164,6 @@ int gams_wave_peaks(gams_gpu_t *h, gams_wave_plan_t *p,
 /* Wait for the last run and copy ctg i's dense rows (either pointer may be NULL). */
 int gams_wave_dense(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t i,
                     uint32_t *gc_count, int8_t *signal);
-/* Tuning/diagnostics: windows per tile (0 = library default), and how many
- * windows of the last run took the exact-order f32 re-evaluation. */
-int gams_wave_plan_set_tile(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tile_windows);
-int gams_wave_exact_count(gams_gpu_t *h, gams_wave_plan_t *p, uint64_t *n_exact);
-/* Diagnostics of the integer decision's guard band (stat.rs:36-38 is an f32 comparison; windows
- * whose integer margin is inside the band are re-evaluated in the reference's exact f32 order).
- * safety (default 1.5, >= 1) multiplies the derived error bound; all_exact != 0 sends every window
- * down the exact path.  Results are identical for every setting -- only the share of windows that
- * take the exact path changes -- which is what the tests check.  Applies to the next run. */
-int gams_wave_plan_set_guard(gams_gpu_t *h, gams_wave_plan_t *p, float safety, int all_exact);
-/* Diagnostics: with stamps on, thread 0 of every workgroup records the shader clock at the
- * kernel's phase boundaries.  mean_cycles[0..5] = mean duration of load+classify, chunk
- * prefix, window counts, z-score, exact re-evaluation, outputs; [6] = whole workgroup;
- * span_cycles = first workgroup start to last workgroup end. */
-int gams_wave_plan_set_stamps(gams_gpu_t *h, gams_wave_plan_t *p, int enable);
-int gams_wave_stamps(gams_gpu_t *h, gams_wave_plan_t *p, double *mean_cycles /* [8] */,
-                     uint64_t *span_cycles);
-/* the raw stamp words: 16 per workgroup (tile), see wave_stamp() in gams_amd/csrc/wave.hip */
-int gams_wave_stamps_raw(gams_gpu_t *h, gams_wave_plan_t *p, uint64_t *out, uint64_t n_words);
 
 /* Convenience, one ctg from host memory (what wave.rs:143-155 computes):
  * gc_count / signal receive n = gams_window_count(len,size,step) items. */

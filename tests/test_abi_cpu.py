@@ -11,15 +11,35 @@ from gams_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    src = open(os.path.join(ROOT, "include", "gams_gpu.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"\b(gams_[a-z0-9_]+)\s*\(", src)
+HEADERS = ("gams_gpu.h", "gams_gpu_diag.h")     # the binding surface, and the measurement / tuning entries
+
+
+def declared_functions(headers=HEADERS):
+    names = []
+    for hdr in headers:
+        src = open(os.path.join(ROOT, "include", hdr)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names += re.findall(r"\b(gams_[a-z0-9_]+)\s*\(", src)
     return sorted(set(names))
 
 
 def test_header_and_binding_agree():
     assert declared_functions() == sorted(_lib.PROTOTYPES)
+
+
+def test_binding_surface_carries_no_lab_bench():
+    """stamps, guard band, taper, tile size, kernel names and stopwatches are declared in
+    gams_gpu_diag.h only; and the library leaves the process environment alone."""
+    main = set(declared_functions(("gams_gpu.h",)))
+    diag = set(declared_functions(("gams_gpu_diag.h",)))
+    assert not (main & diag)
+    for name in ("gams_wave_plan_set_stamps", "gams_wave_stamps", "gams_wave_stamps_raw", "gams_wave_plan_set_guard",
+                 "gams_wave_plan_set_taper", "gams_wave_plan_set_tile", "gams_wave_plan_kernel_name",
+                 "gams_gpu_timer_start", "gams_gpu_timer_stop", "gams_gpu_last_kernel_ms", "gams_wave_exact_count"):
+        assert name in diag and name not in main, name
+    for src in ("api.hip", "wave.hip", "sw.hip", "interval.hip", "gen.hip", "wave_kernels.hpp", "common.hpp"):
+        text = open(os.path.join(ROOT, "gams_amd", "csrc", src)).read()
+        assert "getenv(" not in text and "setenv(" not in text and "putenv(" not in text, src
 
 
 def test_library_loads_and_exports_every_symbol():
@@ -56,7 +76,7 @@ def test_no_gpu_means_loud_failure():
 
 
 def test_header_is_plain_c(tmp_path):
-    """include/gams_gpu.h must compile as C99 (a Rust/C/Go host binds it as a C ABI) and link against the library."""
+    """include/gams_gpu.h and gams_gpu_diag.h must compile as C99 (a Rust/C/Go host binds it as a C ABI) and link against the library."""
     import os
     import subprocess
 
@@ -64,6 +84,7 @@ def test_header_is_plain_c(tmp_path):
     src = tmp_path / "abi.c"
     src.write_text(
         '#include "gams_gpu.h"\n'
+        '#include "gams_gpu_diag.h"\n'
         "int main(void) {\n"
         "    gams_wave_params_t p = {100, 10, 100u, 3.0f, 1.0f};\n"
         "    gams_peak_t pk = {0u, 0u, 0u, 0};\n"

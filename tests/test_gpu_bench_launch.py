@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-QUICK = ["--steps", "6", "--warmup", "2", "--ramp-ms", "5", "--no-cpu", "--no-extra", "--no-secondary"]
+QUICK = ["--steps", "6", "--warmup", "2", "--ramp-ms", "5", "--no-cpu", "--no-extra", "--no-secondary", "--no-e2e"]
 
 
 def _env(extra=None):

@@ -65,6 +65,90 @@ def test_wave_rows_equal_oracle(eng, s288c, kw):
     assert got == exp
 
 
+def test_wave_from_gz_seq_values(eng, s288c):
+    """The path as the reference walks it (wave.rs:134-136 -> redis.rs:142-161): the ctgs' `seq:` values are gzip
+    members; workers inflate them straight into a page-locked image of the device buffer and the DMA follows.
+    Golden I.peaks.tsv byte for byte from gz values (written by Python's gzip, i.e. not by our encoder), the
+    same text as the buffer form on ragged ctgs for 1 / 3 / 16 workers, and the stage clock filled."""
+    import gzip
+
+    ctgs = helpers.gen_ctgs("I", s288c["I"], piece=500000)
+    for c in ctgs:
+        c["gz"] = gzip.compress(bytes(c["seq"]), 1)
+    text, st = host.wave_gz(eng, ctgs, 100, 10, 100, 3.0, 1.0, 0.2, threads=4)
+    assert HEADER + text.decode() == "\n".join(helpers.read_lines("I.peaks.tsv")) + "\n"
+    assert st["inflate_threads"] == 1 and st["peaks"] > 100 and st["total_ms"] > 0     # one ctg: one worker
+    ragged = all_ctgs(s288c, piece=30000) + [dict(id="ctg:Z:1", chr_id="Z", chr_start=7, chr_end=7 + 1100 - 1,
+                                                  seq=bytes(s288c["Mito"][:1100]))]
+    for c in ragged:
+        c["gz"] = host.encode_gz(bytes(c["seq"]))
+    exp = host.wave(eng, ragged)
+    for threads in (1, 3, 16):
+        for sync in (False, True):
+            text, st = host.wave_gz(eng, ragged, threads=threads, sync=sync)
+            assert text.decode() == exp
+            assert st["inflate_threads"] == min(threads, len(ragged))
+    t2, st2 = host.wave_timed(eng, ragged, sync=True)
+    assert t2.decode() == exp and st2["upload_ms"] > 0 and st2["inflate_upload_ms"] == 0
+    # a value that inflates to another length than its ctg record says is refused, whichever way it is off
+    bad = [dict(c) for c in ragged[:3]]
+    bad[1]["gz"] = gzip.compress(bytes(bad[1]["seq"])[:-1], 1)
+    with pytest.raises(host.HostError):
+        host.wave_gz(eng, bad)
+    bad[1]["gz"] = gzip.compress(bytes(bad[1]["seq"]) + b"A", 1)
+    with pytest.raises(host.HostError):
+        host.wave_gz(eng, bad)
+    bad[1]["gz"] = b"\x1f\x8b garbage"
+    with pytest.raises(host.HostError):
+        host.wave_gz(eng, bad)
+    assert host.wave_gz(eng, ragged[:3])[0].decode() == host.wave(eng, ragged[:3])      # the handle is fine afterwards
+
+
+def test_seqset_image_upload_equals_upload_all(eng, s288c):
+    """gams_seqset_layout + gams_seqset_upload_image (a host image of the device buffer, DMA'd in pieces) give
+    the same device bytes as gams_seqset_upload_all: same counts and signals; ranges outside the set refused."""
+    import ctypes as C
+
+    seqs = [bytes(s288c["I"][:70001]), bytes(s288c["Mito"][:30000]), b"ACGT" * 300, bytes(s288c["I"][100000:100257])]
+    ss = engine.SeqSet(eng, seqs)
+    lens = np.array([len(x) for x in seqs], np.uint32)
+    p2 = C.c_void_p()
+    eng.check(eng.lib.gams_seqset_create(eng.h, len(seqs), lens.ctypes.data, C.byref(p2)))
+    off = np.zeros(len(seqs), np.uint64)
+    nbytes = C.c_uint64()
+    eng.check(eng.lib.gams_seqset_layout(eng.h, p2, off.ctypes.data, C.byref(nbytes)))
+    assert off[0] == 0 and np.all(off % 256 == 0) and np.all(np.diff(off.astype(np.int64)) >= lens[:-1])
+    assert nbytes.value >= int(off[-1]) + int(lens[-1])
+    blk = C.c_void_p()
+    eng.check(eng.lib.gams_gpu_host_alloc(eng.h, nbytes.value, C.byref(blk)))
+    img = np.frombuffer((C.c_uint8 * nbytes.value).from_address(blk.value), np.uint8)
+    img[:] = 0x4E
+    for o, sq in zip(off, seqs):
+        img[int(o):int(o) + len(sq)] = np.frombuffer(sq, np.uint8)
+    end = int(off[-1]) + int(lens[-1])
+    cuts = [0, 4097, 4097, 65536, end]
+    for lo, hi in zip(cuts, cuts[1:]):
+        eng.check(eng.lib.gams_seqset_upload_image(eng.h, p2, blk, lo, hi))
+    assert eng.lib.gams_seqset_upload_image(eng.h, p2, blk, 10, nbytes.value + 1) == _lib.EINVAL
+    assert eng.lib.gams_seqset_upload_image(eng.h, p2, blk, 11, 10) == _lib.EINVAL
+    s2 = engine.SeqSet.__new__(engine.SeqSet)
+    s2.eng, s2.p, s2.lengths = eng, p2, lens
+    for sset in (ss, s2):
+        plan = engine.WavePlan(eng, sset, 100, 10, 20, 2.0, 1.0, flags=_lib.WAVE_PEAKS | _lib.WAVE_DENSE)
+        plan.run()
+        got = [plan.dense(c) for c in range(len(seqs))]
+        if sset is ss:
+            ref = got
+        else:
+            for (c0, s0), (c1, s1) in zip(ref, got):
+                assert np.array_equal(c0, c1) and np.array_equal(s0, s1)
+        plan.close()
+    eng.sync()
+    eng.lib.gams_gpu_host_free(eng.h, blk)
+    s2.close()
+    ss.close()
+
+
 def test_wave_short_ctg_reports_the_reference_panic(eng):
     c = dict(id="ctg:X:1", chr_id="X", chr_start=1, chr_end=400, seq=b"ACGT" * 100)
     with pytest.raises(host.HostError) as ei:

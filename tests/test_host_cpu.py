@@ -54,6 +54,40 @@ def test_gzip_framing_of_seq_values():
         host.decode_gz(b"not a gzip member")
 
 
+def test_gzip_batches_on_several_threads_and_damaged_members():
+    """decode_gz of a batch of seq: values on several host threads (the reference inflates inside its --parallel
+    workers, redis.rs:142-161 under wave.rs:288-299); Python's gzip module is the independent codec.  Members
+    whose ISIZE trailer lies, truncated members, a second member behind the first (GzDecoder reads one),
+    values that do not fit the room given."""
+    import gzip
+    import struct
+
+    import helpers
+    import numpy as np
+
+    seqs = helpers.load_s288c()
+    rng = np.random.default_rng(5)
+    raws = [bytes(seqs["I"][a:a + n]) for a, n in ((0, 100000), (100000, 130218), (5, 1), (77, 0), (1000, 65536))]
+    raws += [bytes(rng.integers(0, 256, 30000, dtype=np.uint8)), b"N" * 200000]
+    blobs = [gzip.compress(r, lv) for r, lv in zip(raws, (1, 6, 1, 1, 9, 1, 1))]
+    for threads in (1, 3, 16):
+        out = host.decode_gz_many(blobs, [len(r) for r in raws], threads)
+        assert [o.tobytes() for o in out] == raws
+    # a trailer whose ISIZE lies is a corrupt member (flate2, zlib and libdeflate all check it)
+    good = gzip.compress(raws[0], 1)
+    for lie in (0, 5, 2 * len(raws[0]), 0xFFFFFFFF):
+        with pytest.raises(host.HostError):
+            host.decode_gz(good[:-4] + struct.pack("<I", lie))
+    # a second member behind the first: flate2's GzDecoder reads one member; the single-value form sizes its
+    # output from the LAST four bytes (the short second member's ISIZE here) and has to grow
+    assert host.decode_gz(good + gzip.compress(b"second member", 1)) == raws[0]
+    for bad in (good[:len(good) // 2], good[:17], good[:10] + b"\xff" * 40 + good[50:], b""):
+        with pytest.raises(host.HostError):
+            host.decode_gz(bad)
+    with pytest.raises(host.HostError):
+        host.decode_gz_many([good], [len(raws[0]) - 1], 2)                          # does not fit
+
+
 def test_command_tsv_ctgs_reproduces_the_fixture():
     """tests/cli.rs:214-233 (`gams tsv -s "ctg:*"`: 4 lines, 7 fields, header names) and the rows of
     tests/S288c/ctg.tsv, which the reference made the same way (README.md recipe)."""

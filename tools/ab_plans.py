@@ -58,7 +58,8 @@ for arm in args.arms:
     for k, v in env.items():
         os.environ[k] = v
     ps = [engine.WavePlan(eng, ss, 100, args.step, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS) for ss in sets]
-    for k, v in kv.items():                     # plan.taper=0|1|-1, plan.tile=3072, plan.depth=2: setters of the plan
+    for k, v in kv.items():                     # plan.taper=0|1|-1, plan.tile=3072, plan.depth=2, plan.taper_shape=25050
+                                                # (pct4 * 1000 + pct8; was GAMS_TAPER4/8 in the environment): setters of the plan
         if k.startswith("plan."):
             for p in ps:
                 getattr(p, "set_" + k[5:])(int(v))
