@@ -40,6 +40,7 @@
 #include <type_traits>
 
 #include "wave_kernels.hpp"
+#include "wave_repair.hpp"
 
 
 // =============================================================================
@@ -51,6 +52,9 @@ struct gams_wave_plan {
     gams_wave_params_t prm{};
     uint32_t flags = 0;
     bool serial = false;          // influence != 1
+    bool repair = false;          // ... by speculate-and-repair (wave_repair.hpp): the kernels run as for influence == 1 into
+                                  // the dense rows, zones behind the signals are then walked in parallel
+    float *d_xtab = nullptr;      // repair: xtab[k] = k as f32 / size as f32, [size + 1] (inside arena_fixed)
     bool direct = false;          // halo beyond a tile: one lane per window, no tiling (wave_direct_*_kernel)
     bool wide = false, k16 = false;
     int fast_w = 0;               // W of wave_fast_kernel (0: generic wave_tile_kernel)
@@ -78,6 +82,8 @@ struct gams_wave_plan {
         int8_t *d_dense_sig = nullptr;
         float *d_filtered = nullptr;
         size_t d_dense_cnt_bytes = 0, d_dense_sig_bytes = 0, d_filtered_bytes = 0;
+        uint8_t *d_zone = nullptr;              // repair: one pooled block, carved by wave_zone_carve
+        size_t d_zone_bytes = 0;
         hipEvent_t done = nullptr;              // pipelined mode: recorded behind each run's kernels
         hipEvent_t ran_ev = nullptr;            // lets the readback stream queue behind the last run
         uint64_t seen_upload = 0;               // seqset upload generation this way's stream has waited for
@@ -89,6 +95,8 @@ struct gams_wave_plan {
     int taper_req = -1;                         // gams_wave_plan_set_taper: -1 auto, 0 off, 1 on
     bool taper = false;                         // the tile table ends in W = 8 and W = 4 tiles (wave_fast_taper_kernel)
     int taper4_pct = 25, taper8_pct = 50;       // size of the two tails, % of a round of workgroup slots (gams_wave_plan_set_taper_shape)
+    uint32_t zone_cap_mult = 8;                 // repair: windows of a speculative zone walk, in multiples of lag + 1 (gams_wave_plan_set_zone_cap;
+                                                // 30-Mb chromosome, influence 0.5 / 0.0: x4 4.1 / 6.8 ms, x8 2.8 / 3.5 ms, more: the same)
     uint32_t queue_threads = gams_gpu::kMaxWays;   // host threads gams_wave_run_n queues from (gams_wave_plan_set_queue_threads)
     uint32_t last_way = 0;                      // way of the most recent run
     uint32_t sel_age = 0;                       // readers look at the run `sel_age` before the most recent one
@@ -247,7 +255,7 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
     p->direct = false;
     p->taper = false;
     // fast kernel: 8-bit counts, 32-bit variance math with 24-bit multiplies
-    const bool fast_ok = !p->serial && q.size <= 255 && q.step <= 32 && (uint64_t)q.lag * q.size <= 65535 &&
+    const bool fast_ok = (!p->serial || p->repair) && q.size <= 255 && q.step <= 32 && (uint64_t)q.lag * q.size <= 65535 &&
                          (uint64_t)q.lag * q.size * q.size < (1ull << 24) && q.lag >= 2;
     const bool step1_prm = q.size == 100 && q.step == 1 && wave_baked_kind(q, 28) != 0;
     if (fast_ok && (tw_req == 0 || tw_req == 1024 || tw_req == 2048 || tw_req == 3072 || tw_req == 5120 ||
@@ -298,13 +306,16 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
             p->max_chunks = ((uint32_t)((halo_bytes + (uint64_t)p->tw * q.step + 15) / 16) + 1 + 255u) & ~255u;
             p->k16 = false;
             p->wide = false;
-            p->lds_bytes = wave_fast_lds_bytes(p->max_chunks, (uint32_t)pick, q.lag, (p->flags & GAMS_WAVE_DENSE) != 0);
+            p->lds_bytes = wave_fast_lds_bytes(p->max_chunks, (uint32_t)pick, q.lag,
+                                               (p->flags & GAMS_WAVE_DENSE) != 0 || p->serial);
             // a launch of at least a round and a half of workgroups ends in smaller tiles, unless the host
             // keeps passes in flight (their tails overlap anyway, and the small tiles cost 3-4 % more work)
             const uint32_t slots = 8u * (uint32_t)std::max(h->cus, 1);
             const bool headline = q.size == 100 && q.step == 10 && q.lag == 100;
             const bool want = p->taper_req < 0 ? p->depth == 1 : p->taper_req != 0;
-            p->taper = want && tw_req == 0 && pick == 12 && headline && p->total_windows / p->tw >= slots + slots / 2;
+            // (not for influence != 1: the dense rows are compacted by wave_compact_kernel, which knows one tile size)
+            p->taper = want && !p->serial && tw_req == 0 && pick == 12 && headline &&
+                       p->total_windows / p->tw >= slots + slots / 2;
             if (p->taper)
                 wave_fill_tiles_tapered(p, slots);
             else
@@ -417,6 +428,39 @@ int wave_upload_geometry(gams_gpu_t *h, gams_wave_plan_t *p) {
     return GAMS_OK;
 }
 
+// The repair path's device tables of one way, carved from one pooled block.  Every S1 signal may start a
+// zone and every window may be an S1 signal, so the per-signal tables have one entry per window.
+struct ZoneBufs {
+    uint32_t *blk_cnt;               // S1 signals per block of kZoneBlock rows
+    unsigned long long *blk_off;     // their exclusive prefix (+ 2 totals: all signals, fullest block)
+    uint32_t *zlist;                 // rows of the S1 signals, ascending
+    uint2 *zinfo;                    // per S1 signal: zone end, next S1 signal behind it
+    uint32_t *vlist;                 // per ctg (at its first signal's index): the zones to commit
+    uint32_t *vcount, *pbase;        // per ctg
+    unsigned long long *vstart;      // exclusive prefix of vcount (+ 2 totals)
+    size_t bytes;
+};
+ZoneBufs wave_zone_carve(uint8_t *base, uint64_t total_windows, uint32_t n_ctg) {
+    const size_t nb = (size_t)((total_windows + kZoneBlock - 1) / kZoneBlock);
+    size_t o = 0;
+    auto take = [&](size_t b) {
+        uint8_t *q = base ? base + o : nullptr;
+        o += wave_align256(b);
+        return q;
+    };
+    ZoneBufs z{};
+    z.blk_cnt = reinterpret_cast<uint32_t *>(take(std::max<size_t>(nb, 1) * 4));
+    z.blk_off = reinterpret_cast<unsigned long long *>(take((nb + 2) * 8));
+    z.zlist = reinterpret_cast<uint32_t *>(take(std::max<uint64_t>(total_windows, 1) * 4));
+    z.zinfo = reinterpret_cast<uint2 *>(take(std::max<uint64_t>(total_windows, 1) * 8));
+    z.vlist = reinterpret_cast<uint32_t *>(take(std::max<uint64_t>(total_windows, 1) * 4));
+    z.vcount = reinterpret_cast<uint32_t *>(take(std::max<size_t>(n_ctg, 1) * 4));
+    z.pbase = reinterpret_cast<uint32_t *>(take(std::max<size_t>(n_ctg, 1) * 4));
+    z.vstart = reinterpret_cast<unsigned long long *>(take(((size_t)n_ctg + 2) * 8));
+    z.bytes = o;
+    return z;
+}
+
 // per-way buffers that do not depend on the tiling: counter ring, dense rows, filtered[]
 int wave_alloc_ways(gams_gpu_t *h, gams_wave_plan_t *p) {
     const uint64_t base = std::max<uint64_t>(p->total_windows, 1);
@@ -437,9 +481,16 @@ int wave_alloc_ways(gams_gpu_t *h, gams_wave_plan_t *p) {
             GAMS_HIP(h, gams_pool_alloc(h, false, base, reinterpret_cast<void **>(&w.d_dense_sig),
                                         &w.d_dense_sig_bytes));
         }
-        if (p->serial && !w.d_filtered)
+        if (p->serial && !p->repair && !w.d_filtered)
             GAMS_HIP(h, gams_pool_alloc(h, false, base * sizeof(float), reinterpret_cast<void **>(&w.d_filtered),
                                         &w.d_filtered_bytes));
+        if (p->repair && !w.d_zone) {
+            const hipError_t e = gams_pool_alloc(h, false, wave_zone_carve(nullptr, p->total_windows, p->set->n_ctg).bytes,
+                                                 reinterpret_cast<void **>(&w.d_zone), &w.d_zone_bytes);
+            if (e == hipErrorOutOfMemory)
+                return gams_fail(h, GAMS_ENOMEM, "wave: no memory for the influence != 1 tables (16 B per window)");
+            GAMS_HIP(h, e);
+        }
     }
     return GAMS_OK;
 }
@@ -529,6 +580,10 @@ int gams_wave_plan_create(gams_gpu_t *h, gams_seqset_t *s, const gams_wave_param
         base += (uint64_t)n;
     }
     p->total_windows = base;
+    // influence != 1: speculate-and-repair while a wavefront's 64 rings of lag + 2 floats fit the LDS and the
+    // dense rows can be indexed with 32 bits; the one-wavefront-per-ctg recurrence beyond that
+    p->repair = p->serial && params->lag >= 2 && ((size_t)params->lag + 2) * 256 <= 150 * 1024 &&
+                base < 0xFFFFFFFFull - 4 * kZoneBlock;
     int rc = wave_build_geometry(h, p, 0);
     if (rc != GAMS_OK) {
         delete p;
@@ -551,10 +606,18 @@ int gams_wave_plan_create(gams_gpu_t *h, gams_seqset_t *s, const gams_wave_param
     {
         const size_t b_ctgs = wave_align256(std::max<size_t>(s->n_ctg, 1) * sizeof(WaveCtgDev));
         const size_t b_const = wave_align256((size_t)params->size + 1);
-        PLAN_HIP(gams_pool_alloc(h, false, b_ctgs + b_const, reinterpret_cast<void **>(&p->arena_fixed),
+        const size_t b_xtab = p->repair ? wave_align256(((size_t)params->size + 1) * sizeof(float)) : 0;
+        PLAN_HIP(gams_pool_alloc(h, false, b_ctgs + b_const + b_xtab, reinterpret_cast<void **>(&p->arena_fixed),
                                  &p->arena_fixed_bytes));
         p->d_ctgs = reinterpret_cast<WaveCtgDev *>(p->arena_fixed);
         p->d_const_sig = reinterpret_cast<int8_t *>(p->arena_fixed + b_ctgs);
+        if (p->repair) {
+            // the data value of a window with k G/C bases, as the reference computes it: k as f32 / size as f32
+            p->d_xtab = reinterpret_cast<float *>(p->arena_fixed + b_ctgs + b_const);
+            std::vector<float> xt((size_t)params->size + 1);
+            for (size_t k = 0; k < xt.size(); ++k) xt[k] = (float)k / (float)params->size;
+            PLAN_HIP(hipMemcpy(p->d_xtab, xt.data(), xt.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     }
     if (s->n_ctg)
         PLAN_HIP(hipMemcpy(p->d_ctgs, p->ctgs.data(), s->n_ctg * sizeof(WaveCtgDev), hipMemcpyHostToDevice));
@@ -592,6 +655,7 @@ void gams_wave_plan_destroy(gams_gpu_t *h, gams_wave_plan_t *p) {
         gams_pool_free(h, false, w.d_dense_cnt, w.d_dense_cnt_bytes);
         gams_pool_free(h, false, w.d_dense_sig, w.d_dense_sig_bytes);
         gams_pool_free(h, false, w.d_filtered, w.d_filtered_bytes);
+        gams_pool_free(h, false, w.d_zone, w.d_zone_bytes);
         if (w.done) (void)hipEventDestroy(w.done);
         if (w.ran_ev) (void)hipEventDestroy(w.ran_ev);
     }
@@ -674,7 +738,7 @@ static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
     a.max_chunks = p->max_chunks;
     a.max_win = p->max_win;
     a.flags = p->serial ? GAMS_WAVE_DENSE : p->flags;
-    a.no_signal = (q.lag < 2 || p->serial) ? 1u : 0u;
+    a.no_signal = (q.lag < 2 || (p->serial && !p->repair)) ? 1u : 0u;
     a.thr = q.threshold;
     a.thr_abs = std::fabs(q.threshold);
     a.fsize = (float)q.size;
@@ -704,7 +768,7 @@ static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
         hipLaunchKernelGGL(wave_direct_count_kernel, dim3(blocks), dim3(256), 0, st, p->set->d_seq, p->d_ctgs,
                            p->set->n_ctg, total, (uint32_t)q.size, (uint32_t)q.step, w.d_dense_cnt);
         GAMS_HIP(h, hipGetLastError());
-        if (!p->serial) {
+        if (!p->serial || p->repair) {
             hipLaunchKernelGGL(wave_direct_signal_kernel, dim3(blocks), dim3(256), 0, st, p->d_ctgs, p->set->n_ctg,
                                total, w.d_dense_cnt, w.d_dense_sig, q.lag, q.threshold, (float)q.size,
                                q.lag < 2 ? 1u : 0u);
@@ -761,7 +825,49 @@ static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
                            p->d_tiles, p->tw, w.d_dense_cnt, w.d_dense_sig, w.d_peaks, p->tile_cap, w.d_tile_cnt);
         GAMS_HIP(h, hipGetLastError());
     }
-    if (p->serial) {
+    if (p->repair) {
+        // influence != 1, speculate-and-repair (wave_repair.hpp): the dense rows hold the counts and the S1
+        // signals; everything below is queued on the way's stream, no host wait
+        const uint64_t total = p->total_windows;
+        const ZoneBufs z = wave_zone_carve(w.d_zone, total, p->set->n_ctg);
+        const unsigned nb = (unsigned)((total + kZoneBlock - 1) / kZoneBlock);
+        ZoneArgs za{};
+        za.ctgs = p->d_ctgs;
+        za.n_ctg = p->set->n_ctg;
+        za.cnt = w.d_dense_cnt;
+        za.sig = w.d_dense_sig;
+        za.xtab = p->d_xtab;
+        za.zlist = z.zlist;
+        za.totals = z.blk_off + nb;
+        za.zinfo = z.zinfo;
+        za.lag = q.lag;
+        za.cap = (p->zone_cap_mult * (q.lag + 1u) + 1u) & ~1u;   // windows of a speculative zone walk (even: two per trip); longer zones are the resolver's
+        za.thr = q.threshold;
+        za.influence = q.influence;
+        za.n_xtab = (uint32_t)q.size + 1u;
+        const size_t ring_bytes = ((size_t)q.lag + 2) * 64 * sizeof(float) + (za.n_xtab <= kXtabLds ? za.n_xtab * sizeof(float) : 0);
+        const size_t resolve_bytes = (size_t)((q.lag + 2u + 63u) & ~63u) * sizeof(float) + (size_t)kResolveStage * sizeof(uint2);
+        const unsigned grid = (unsigned)std::max(h->cus, 1) * 8u;
+        GAMS_HIP(h, gams_lds_attr(h, reinterpret_cast<const void *>(zone_spec_kernel), ring_bytes));
+        GAMS_HIP(h, gams_lds_attr(h, reinterpret_cast<const void *>(zone_commit_kernel), ring_bytes));
+        GAMS_HIP(h, gams_lds_attr(h, reinterpret_cast<const void *>(zone_resolve_kernel), resolve_bytes));
+        hipLaunchKernelGGL(zone_count_kernel, dim3(nb), dim3(256), 0, st, w.d_dense_sig, total, z.blk_cnt);
+        hipLaunchKernelGGL(wave_offsets_kernel, dim3(1), dim3(1024), 0, st, z.blk_cnt, nb, z.blk_off, z.blk_off + nb);
+        hipLaunchKernelGGL(zone_scatter_kernel, dim3(nb), dim3(256), 0, st, w.d_dense_sig, total, z.blk_off, z.zlist);
+        hipLaunchKernelGGL(zone_spec_kernel, dim3(grid), dim3(64), ring_bytes, st, za);
+        hipLaunchKernelGGL(zone_resolve_kernel, dim3(std::min<unsigned>(za.n_ctg, grid)), dim3(64), resolve_bytes, st, za,
+                           z.vlist, z.vcount, z.pbase);
+        hipLaunchKernelGGL(wave_offsets_kernel, dim3(1), dim3(1024), 0, st, z.vcount, za.n_ctg, z.vstart,
+                           z.vstart + za.n_ctg);
+        hipLaunchKernelGGL(zone_commit_kernel, dim3(grid), dim3(64), ring_bytes, st, za, z.vlist, z.pbase, z.vstart,
+                           z.vstart + za.n_ctg);
+        GAMS_HIP(h, hipGetLastError());
+        if (p->flags & GAMS_WAVE_PEAKS) {
+            hipLaunchKernelGGL(wave_compact_kernel, dim3((unsigned)p->tiles.size()), dim3(256), 0, st, p->d_ctgs,
+                               p->d_tiles, p->tw, w.d_dense_cnt, w.d_dense_sig, w.d_peaks, p->tile_cap, w.d_tile_cnt);
+            GAMS_HIP(h, hipGetLastError());
+        }
+    } else if (p->serial) {
         const uint32_t n = p->set->n_ctg;
         if (q.lag + 1u <= kSerialRing) {
             // one wavefront per ctg, the last lag + 1 filtered values in an LDS ring
@@ -1008,6 +1114,13 @@ int gams_wave_plan_set_taper_shape(gams_gpu_t *h, gams_wave_plan_t *p, int pct4,
     return rc;
 }
 
+int gams_wave_plan_set_zone_cap(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t mult) {
+    if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_plan_set_zone_cap: null argument");
+    if (mult < 1 || mult > 4096) return gams_fail(h, GAMS_EINVAL, "wave_plan_set_zone_cap: 1..4096");
+    p->zone_cap_mult = mult;
+    return GAMS_OK;
+}
+
 int gams_wave_plan_set_queue_threads(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t n) {
     if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_plan_set_queue_threads: null argument");
     if (n < 1 || n > (uint32_t)gams_gpu::kMaxWays)
@@ -1024,7 +1137,9 @@ int gams_wave_plan_kernel_name(gams_gpu_t *h, gams_wave_plan_t *p, char *buf, si
     const bool baked = kind != 0;
     const char *nt = p->set->bytes > kStreamBytes ? "true" : "false";
     std::string name;
-    if (p->serial)
+    if (p->repair)
+        name = "zone_spec_kernel";     // of the pass's kernels (counts + S1 signals, zones, commit) the one that takes longest
+    else if (p->serial)
         name = q.lag + 1u <= kSerialRing ? "wave_serial_wave_kernel" : "wave_serial_kernel";
     else if (p->direct)
         name = "wave_direct_count_kernel + wave_direct_signal_kernel";

@@ -1204,7 +1204,7 @@ __global__ __launch_bounds__(256) void wave_compact_kernel(const WaveCtgDev *ctg
     const WaveTile tl = tiles[blockIdx.x];
     const struct { uint64_t win_base; uint32_t n_win; } cg = {tl.win_base, tl.n_win};
     const uint32_t w0 = tl.w0, w1 = min(w0 + tw, cg.n_win);
-    const uint32_t R = tw >> 8;
+    const uint32_t R = (tw + 255u) >> 8;       // the baked fast tiles hold 256*W - lag - 1 windows: not a multiple of 256
     uint64_t sigbits = 0;
     for (uint32_t r = 0; r < R; ++r) {
         const uint32_t i = w0 + (r << 8) + tid;

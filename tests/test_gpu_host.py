@@ -134,7 +134,7 @@ def test_seqset_image_upload_equals_upload_all(eng, s288c):
     s2 = engine.SeqSet.__new__(engine.SeqSet)
     s2.eng, s2.p, s2.lengths = eng, p2, lens
     for sset in (ss, s2):
-        plan = engine.WavePlan(eng, sset, 100, 10, 20, 2.0, 1.0, flags=_lib.WAVE_PEAKS | _lib.WAVE_DENSE)
+        plan = engine.WavePlan(eng, sset, 100, 10, 12, 2.0, 1.0, flags=_lib.WAVE_PEAKS | _lib.WAVE_DENSE)
         plan.run()
         got = [plan.dense(c) for c in range(len(seqs))]
         if sset is ss:

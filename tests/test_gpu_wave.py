@@ -580,8 +580,9 @@ def test_overflowing_tile_regrows_to_the_fullest_tile(eng, s288c):
 @pytest.mark.parametrize("lag,infl,thr", [(100, 0.5, 3.0), (64, 0.0, 2.0), (65, 0.25, 2.5), (7, 0.9, 1.5), (200, 1.5, 3.0),
                                           (128, -0.5, 2.0)])
 def test_influence_recurrence_one_wave_per_ctg(eng, s288c, lag, infl, thr):
-    """influence != 1 (stat.rs:42): the filtered[] recurrence, one wavefront per ctg with an LDS ring; several ctgs
-    of different lengths in one batch, lags around the 64-lane chunk size, influences outside [0, 1]."""
+    """influence != 1 (stat.rs:42): the filtered[] recurrence (round 2: one wavefront per ctg with an LDS ring; round 3:
+    speculate-and-repair, one lane per zone); several ctgs of different lengths in one batch, lags around the 64-lane
+    chunk size, influences outside [0, 1]."""
     seqs = [bytes(s288c["Mito"][:40000]), synth(25000, 71).tobytes(), synth(lag * 10 + 99, 72).tobytes(),
             bytes(s288c["I"][:60000])]
     ss = engine.SeqSet(eng, seqs)
@@ -624,7 +625,7 @@ def test_plan_kernel_name_follows_the_plan(eng):
     assert names["step 1, 5120"] == "wave_fast_kernel<20, 100, 1, 100, false>"
     assert names["step 1, 7168"] == "wave_fast_kernel<28, 100, 1, 100, false>"
     assert names[(50, 7, 33, 1.0)] == "wave_fast_kernel<4, 0, 0, 0, false>"
-    assert names[(100, 10, 100, 0.5)] == "wave_serial_wave_kernel"
+    assert names[(100, 10, 100, 0.5)] == "zone_spec_kernel"
     assert names[(100, 1000, 100, 1.0)].startswith("wave_direct_count_kernel")
 
 
@@ -693,3 +694,74 @@ def test_plans_sharing_a_kernel_function_keep_their_lds(eng, s288c):
         a.close()
         b.close()
     ss.close()
+
+
+def test_thresholding_sample_through_the_device(eng):
+    """The reference's own unit test of the detector (stat.rs:58-81: 74 values, lag 30, threshold 5, influence 0)
+    through the GPU path.  Its values have one decimal and reach 5.0; gc_content cannot exceed 1, so the series is
+    scaled by 1/10 -- value y becomes a window of 100 bases with 10*y G's (k as f32 / 100 as f32) -- which leaves
+    every comparison of the (scale-free) detector where it was: the expected signals are the reference's vector."""
+    data = [1.0, 1.0, 1.1, 1.0, 0.9, 1.0, 1.0, 1.1, 1.0, 0.9, 1.0, 1.1, 1.0, 1.0, 0.9, 1.0, 1.0, 1.1, 1.0, 1.0,
+            1.0, 1.0, 1.1, 0.9, 1.0, 1.1, 1.0, 1.0, 0.9, 1.0, 1.1, 1.0, 1.0, 1.1, 1.0, 0.8, 0.9, 1.0, 1.2, 0.9,
+            1.0, 1.0, 1.1, 1.2, 1.0, 1.5, 1.0, 3.0, 2.0, 5.0, 3.0, 2.0, 1.0, 1.0, 1.0, 0.9, 1.0, 1.0, 3.0, 2.6,
+            4.0, 3.0, 3.2, 2.0, 1.0, 1.0, 0.8, 4.0, 4.0, 2.0, 2.5, 1.0, 1.0, 1.0]
+    exp = [0] * 45 + [1, 0, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0]
+    assert len(data) == len(exp) == 74
+    seq = b"".join(b"G" * round(10 * y) + b"A" * (100 - round(10 * y)) for y in data)
+    for step_size, seqs in ((100, [seq]), (100, [seq, synth(30000, 3).tobytes(), seq])):
+        ss = engine.SeqSet(eng, seqs)
+        plan = engine.WavePlan(eng, ss, 100, step_size, 30, 5.0, 0.0, flags=_lib.WAVE_PEAKS | _lib.WAVE_DENSE)
+        assert plan.kernel_name() == "zone_spec_kernel"
+        plan.run()
+        pk = plan.peaks()
+        for c, sq in enumerate(seqs):
+            cnt, sig = plan.dense(c)
+            if sq is seq:
+                assert cnt.tolist() == [round(10 * y) for y in data]
+                assert sig.tolist() == exp
+                assert pk[pk["ctg"] == c]["window"].tolist() == [i for i, v in enumerate(exp) if v]
+            _, _, osig = ora.wave_windows(sq, 100, step_size, 30, 5.0, 0.0)
+            assert np.array_equal(sig.astype(np.int32), osig)
+        plan.close()
+        ss.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_influence_fuzz_against_the_oracle(eng, s288c, seed):
+    """Random (size, step, lag, threshold, influence) with influence != 1 on ragged batches: thresholds low enough
+    that most windows signal (zones that run into each other, zones beyond the speculative cap, which the
+    resolver walks itself), lags at the edge of the repair path (lag 638 is the last one; 639 takes the
+    one-wavefront-per-ctg recurrence), sizes beyond 255 (generic tile kernel), steps beyond a tile (untiled kernels)."""
+    rng = np.random.default_rng(1000 + seed)
+    pool = [bytes(s288c["I"][:90_000]), synth(33_333, 40 + seed).tobytes(), bytes(s288c["Mito"][:20_000]),
+            synth(8_000, 50 + seed, gc=0.5, nrate=0.02).tobytes(), (b"ACGT" * 3000 + b"N" * 500 + b"GGCC" * 2000)]
+    cases = []
+    for _ in range(7):
+        size = int(rng.choice([20, 50, 100, 100, 100, 256, 300]))
+        step = int(rng.choice([1, 3, 10, 10, 25, 50, 2000]))
+        lag = int(rng.choice([2, 3, 5, 30, 64, 100, 100, 200, 401]))
+        thr = float(rng.choice([0.3, 1.0, 2.0, 3.0, 3.0, 5.0]))
+        infl = float(rng.choice([0.0, 0.0, 0.25, 0.5, 0.9, 0.999, 1.5, -0.5]))
+        cases.append((size, step, lag, thr, infl))
+    cases += [(100, 10, 638, 2.0, 0.5), (100, 10, 639, 2.0, 0.5)] if seed == 0 else []
+    cases += [(100, 10, 100, 0.05, 0.0), (100, 1, 50, 1.0, 0.0)] if seed == 1 else []
+    for size, step, lag, thr, infl in cases:
+        seqs = [sq for sq in pool if (len(sq) - size) // step + 1 >= lag]
+        if not seqs:
+            continue
+        ss = engine.SeqSet(eng, seqs)
+        plan = engine.WavePlan(eng, ss, size, step, lag, thr, infl, flags=_lib.WAVE_PEAKS | _lib.WAVE_DENSE)
+        for rep in range(2):                   # twice: the second pass runs over the first one's tables
+            plan.run()
+        pk = plan.peaks()
+        for c, sq in enumerate(seqs):
+            ocnt, _, osig = ora.wave_windows(sq, size, step, lag, thr, infl)
+            cnt, sig = plan.dense(c)
+            assert np.array_equal(cnt, ocnt), (size, step, lag, thr, infl, c)
+            bad = np.flatnonzero(sig.astype(np.int32) != osig)
+            assert bad.size == 0, (size, step, lag, thr, infl, c, bad[:5], sig[bad[:5]], osig[bad[:5]])
+            idx = np.flatnonzero(osig)
+            mine = pk[pk["ctg"] == c]
+            assert np.array_equal(mine["window"], idx) and np.array_equal(mine["signal"], osig[idx])
+        plan.close()
+        ss.close()
