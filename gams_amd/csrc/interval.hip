@@ -26,7 +26,7 @@
 
 #include "common.hpp"
 
-#include <rocprim/rocprim.hpp>   // the one library primitive of this file: the segmented LSD radix sort
+#include <rocprim/rocprim.hpp>   // the segmented LSD radix sort, for groups beyond a workgroup (index_build_kernel does the others)
 
 #include <algorithm>
 #include <atomic>
@@ -568,6 +568,302 @@ __global__ __launch_bounds__(256) void index_bk_kernel(const uint32_t *off32, ui
     fill(stops_sorted, G.bk_stop, bk_stop);
 }
 
+// ---- the whole build of ONE group in one workgroup (groups of at most kBuildCap intervals) --------------
+// A group of idx:rg:{ctg} / idx:ctg:{chr} is a few thousand intervals: it fits a workgroup's LDS several times
+// over, so Lapper::new (redis.rs:253,299: intervals.sort(), the stops sorted on their own, max_len) and every
+// table derived from the sorted arrays are made where the data already is, with one pass over HBM in and one
+// out -- against eight radix passes of a generic 64-bit segmented sort plus five kernels that each search the
+// sorted arrays in global memory again (2.4 ms per 1.25e7 intervals in 4,000 groups).
+//   sort      bitonic network over N = 2^ceil(log2 n) slots on the triple (start, stop, position in the
+//             caller's order): the position breaks ties, which makes the network's result the STABLE order of
+//             intervals.sort(); the stops ride along as a second, keys-only network in the same stages
+//             (one barrier per stage for both);
+//   outputs   ascending starts, 16-B scan records, sorted stops, max_len, the group's directory headers,
+//             the bucket directory (one lower bound per slot, in LDS) and the count path's cell records.
+constexpr uint32_t kBuildCap = 8192;
+template <uint32_t CAP, uint32_t T>
+__global__ __launch_bounds__(T) void index_build_kernel(const uint32_t *off32, uint32_t n_groups, const uint32_t *starts,
+                                                        const uint32_t *stops, uint32_t *lstart, IvRec *lrec,
+                                                        uint32_t *stops_sorted, IndexGroup *groups, CountGroup *cgroups,
+                                                        uint32_t *dir_start, BkRec *bk_start, BkRec *bk_stop) {
+    extern __shared__ __align__(16) unsigned char smem_b[];
+    uint64_t *key = reinterpret_cast<uint64_t *>(smem_b);            // (start << 32) | stop
+    uint32_t *skey = reinterpret_cast<uint32_t *>(key + CAP);        // stops, sorted on their own
+    uint16_t *pos = reinterpret_cast<uint16_t *>(skey + CAP);        // position in the caller's order
+    uint32_t *scr = reinterpret_cast<uint32_t *>(pos + CAP);         // 96 words: reductions [0, 64), the group record's parameters [64, 96)
+    const uint32_t tid = threadIdx.x;
+    const uint32_t g = blockIdx.x;
+    if (g >= n_groups) return;
+    const uint32_t lo = off32[g], n = off32[g + 1] - lo;
+    uint32_t N = 4;
+    while (N < n) N <<= 1;
+    // The ranges of a real group are narrow (a ctg's coordinates: 20-odd bits): when (start - min start),
+    // (stop - min stop) and the position fit 64 bits together, the triple is ONE word -- unique, so no tie
+    // logic -- and a compare-exchange is two 8-B reads, one compare, two 8-B writes.  Otherwise the triple
+    // stays (64-bit key, 16-bit position).
+    uint32_t smin = ~0u, smax = 0u, tmin = ~0u, tmax = 0u;
+    for (uint32_t i = tid; i < n; i += T) {
+        const uint32_t a = starts[lo + i], b = stops[lo + i];
+        smin = min(smin, a);
+        smax = max(smax, a);
+        tmin = min(tmin, b);
+        tmax = max(tmax, b);
+    }
+    for (int d = 32; d; d >>= 1) {
+        smin = min(smin, (uint32_t)__shfl_xor((int)smin, d, 64));
+        smax = max(smax, (uint32_t)__shfl_xor((int)smax, d, 64));
+        tmin = min(tmin, (uint32_t)__shfl_xor((int)tmin, d, 64));
+        tmax = max(tmax, (uint32_t)__shfl_xor((int)tmax, d, 64));
+    }
+    if ((tid & 63u) == 0) {
+        scr[(tid >> 6) * 4u + 0u] = smin;     // T / 64 <= 16 waves: scr[0..63] (the parameters below live behind them)
+        scr[(tid >> 6) * 4u + 1u] = smax;
+        scr[(tid >> 6) * 4u + 2u] = tmin;
+        scr[(tid >> 6) * 4u + 3u] = tmax;
+    }
+    __syncthreads();
+    for (uint32_t w = 0; w < T / 64u; ++w) {
+        smin = min(smin, scr[w * 4u + 0u]);
+        smax = max(smax, scr[w * 4u + 1u]);
+        tmin = min(tmin, scr[w * 4u + 2u]);
+        tmax = max(tmax, scr[w * 4u + 3u]);
+    }
+    __syncthreads();
+    const uint32_t bs = n ? 32u - (uint32_t)__clz((int)((smax - smin) | 1u)) : 1u;
+    const uint32_t bt = n ? 32u - (uint32_t)__clz((int)((tmax - tmin) | 1u)) : 1u;
+    const uint32_t bp = 32u - (uint32_t)__clz((int)((N - 1u) | 1u));
+    const bool one_word = bs + bt + bp <= 64u;
+    for (uint32_t i = tid; i < N; i += T) {
+        if (i < n) {
+            const uint32_t a = starts[lo + i], b = stops[lo + i];
+            key[i] = one_word ? ((uint64_t)(a - smin) << (bt + bp)) | ((uint64_t)(b - tmin) << bp) | i
+                              : ((uint64_t)a << 32) | b;
+            skey[i] = b;
+            pos[i] = (uint16_t)i;
+        } else {
+            key[i] = ~0ull;                 // pads sort behind every interval: equal keys are ordered by position
+            skey[i] = ~0u;
+            pos[i] = 0xFFFFu;
+        }
+    }
+    __syncthreads();
+    if (one_word) {
+        // Slots come in blocks of four (block o = slots 4o .. 4o+3, one thread each): the stages with j = 2 and j = 1 of every level (and
+        // the levels k = 2 and k = 4 entirely) never leave them, so they run in registers between one 16-B/32-B
+        // read and one write per array -- two barriers and four LDS round trips less per level.
+        auto cex = [](uint64_t &x, uint64_t &y, bool up) {
+            if ((x > y) == up && x != y) {
+                const uint64_t t_ = x;
+                x = y;
+                y = t_;
+            }
+        };
+        auto cex32 = [](uint32_t &x, uint32_t &y, bool up) {
+            if ((x > y) == up && x != y) {
+                const uint32_t t_ = x;
+                x = y;
+                y = t_;
+            }
+        };
+        auto local = [&](uint32_t k) {            // k == 0: levels 2 and 4 from scratch; else stages j = 2, 1 of level k >= 8
+            for (uint32_t o = tid; o < (N >> 2); o += T) {
+                uint64_t *kp = key + 4u * o;
+                uint32_t *sp = skey + 4u * o;
+                uint64_t a0 = kp[0], a1 = kp[1], a2 = kp[2], a3 = kp[3];
+                uint4 sv = *reinterpret_cast<uint4 *>(sp);
+                const bool up = k ? ((4u * o) & k) == 0u : ((4u * o) & 4u) == 0u;
+                if (k == 0u) {                     // level 2: pairs (0,1) ascending, (2,3) descending
+                    cex(a0, a1, true);
+                    cex(a2, a3, false);
+                    cex32(sv.x, sv.y, true);
+                    cex32(sv.z, sv.w, false);
+                }
+                cex(a0, a2, up);                   // j = 2
+                cex(a1, a3, up);
+                cex(a0, a1, up);                   // j = 1
+                cex(a2, a3, up);
+                cex32(sv.x, sv.z, up);
+                cex32(sv.y, sv.w, up);
+                cex32(sv.x, sv.y, up);
+                cex32(sv.z, sv.w, up);
+                kp[0] = a0;
+                kp[1] = a1;
+                kp[2] = a2;
+                kp[3] = a3;
+                *reinterpret_cast<uint4 *>(sp) = sv;
+            }
+            __syncthreads();
+        };
+        local(0u);
+        for (uint32_t k = 8; k <= N; k <<= 1) {
+            for (uint32_t j = k >> 1; j >= 4u; j >>= 1) {
+                for (uint32_t t = tid; t < (N >> 1); t += T) {
+                    const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u));   // bit j clear
+                    const uint32_t q = i | j;
+                    const bool up = (i & k) == 0u;
+                    const uint64_t ka = key[i], kb = key[q];
+                    if ((ka > kb) == up && ka != kb) {
+                        key[i] = kb;
+                        key[q] = ka;
+                    }
+                    const uint32_t sa = skey[i], sb = skey[q];
+                    if ((sa > sb) == up && sa != sb) {
+                        skey[i] = sb;
+                        skey[q] = sa;
+                    }
+                }
+                __syncthreads();
+            }
+            local(k);
+        }
+        // back to (start << 32 | stop) and the position, in place
+        const uint64_t mt = bt >= 32u ? 0xFFFFFFFFull : (1ull << bt) - 1ull, mp = (1ull << bp) - 1ull;
+        for (uint32_t i = tid; i < n; i += T) {
+            const uint64_t c = key[i];
+            const uint32_t a = (uint32_t)(c >> (bt + bp)) + smin, b = (uint32_t)((c >> bp) & mt) + tmin;
+            key[i] = ((uint64_t)a << 32) | b;
+            pos[i] = (uint16_t)(c & mp);
+        }
+        __syncthreads();
+    } else {
+        for (uint32_t k = 2; k <= N; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = tid; t < (N >> 1); t += T) {
+                    const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u));   // bit j clear
+                    const uint32_t q = i | j;
+                    const bool up = (i & k) == 0u;
+                    const uint64_t ka = key[i], kb = key[q];
+                    const uint32_t pa = pos[i], pb = pos[q];
+                    const bool gt = ka > kb || (ka == kb && pa > pb);
+                    if (gt == up) {
+                        key[i] = kb;
+                        key[q] = ka;
+                        pos[i] = (uint16_t)pb;
+                        pos[q] = (uint16_t)pa;
+                    }
+                    const uint32_t sa = skey[i], sb = skey[q];
+                    if ((sa > sb) == up && sa != sb) {
+                        skey[i] = sb;
+                        skey[q] = sa;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // sorted arrays out; max(stop - start)
+    uint32_t ml = 0;
+    for (uint32_t i = tid; i < n; i += T) {
+        const uint64_t kk = key[i];
+        const uint32_t a = (uint32_t)(kk >> 32), b = (uint32_t)kk;
+        lstart[lo + i] = a;
+        lrec[lo + i] = IvRec{a, b, (uint64_t)lo + pos[i]};
+        stops_sorted[lo + i] = skey[i];
+        if (b > a) ml = max(ml, b - a);
+    }
+    for (int d = 32; d; d >>= 1) ml = max(ml, (uint32_t)__shfl_xor((int)ml, d, 64));
+    if ((tid & 63u) == 0) scr[tid >> 6] = ml;
+    __syncthreads();
+    if (tid == 0) {
+        for (uint32_t w = 1; w < T / 64u; ++w) ml = max(ml, scr[w]);
+        IndexGroup G;
+        G.off = lo;
+        G.n = n;
+        G.maxlen = ml;
+        const KeyDir none{0u, 0u, 0u, 0u};
+        const uint32_t s0 = n ? (uint32_t)(key[0] >> 32) : 0u, s1 = n ? (uint32_t)(key[n - 1] >> 32) : 0u;
+        const uint32_t t0 = n ? skey[0] : 0u, t1 = n ? skey[n - 1] : 0u;
+        G.start = n ? dir_params(s0, s1, n) : none;
+        G.stop = n ? dir_params(t0, t1, n) : none;
+        G.bk_start = n ? dir_params(min(s0, t0), max(s1, t1), (n >> kCellShift) + 1u) : none;
+        G.bk_stop = G.bk_start;
+        groups[g] = G;
+        cgroups[g] = CountGroup{lo, n, G.bk_start.key0, G.bk_start.nb, G.bk_stop.key0, G.bk_stop.nb, G.bk_start.shift,
+                                G.bk_stop.shift};
+        scr[64] = G.start.key0;
+        scr[65] = G.start.shift;
+        scr[66] = G.start.nb;
+        scr[67] = G.bk_start.key0;
+        scr[68] = G.bk_start.shift;
+        scr[69] = G.bk_start.nb;
+    }
+    __syncthreads();
+    if (n == 0) {
+        if (tid == 0) dir_start[(uint64_t)lo + g] = 0u;
+        return;
+    }
+    // bucket directory over the starts (locate): slot b of the group's n + 1 at dir_start[lo + g + b]
+    {
+        const uint32_t key0 = scr[64], shift = scr[65], nb = scr[66];
+        for (uint32_t b = tid; b <= nb; b += T) {
+            uint32_t r = n;
+            if (b < nb) {
+                const uint64_t edge = (uint64_t)key0 + ((uint64_t)b << shift);
+                uint32_t a = 0, z = n;
+                while (a < z) {
+                    const uint32_t mid = a + ((z - a) >> 1);
+                    if ((key[mid] >> 32) < edge)
+                        a = mid + 1;
+                    else
+                        z = mid;
+                }
+                r = a;
+            }
+            dir_start[(uint64_t)lo + g + b] = r;
+        }
+    }
+    // cell records of the count path: cell b of the group at (lo >> kCellShift) + 2g + b, the starts' and the
+    // stops' record side by side
+    {
+        const uint32_t key0 = scr[67], shift = scr[68], nb = scr[69];
+        const uint64_t cell0 = (uint64_t)(lo >> kCellShift) + 2ull * g;
+        for (uint32_t b = tid; b < nb; b += T) {
+            const uint64_t edge = (uint64_t)key0 + ((uint64_t)b << shift);
+            BkRec rs, rt;
+            {
+                uint32_t a = 0, z = n;
+                while (a < z) {
+                    const uint32_t mid = a + ((z - a) >> 1);
+                    if ((key[mid] >> 32) < edge)
+                        a = mid + 1;
+                    else
+                        z = mid;
+                }
+                rs.rank = a;
+#pragma unroll
+                for (uint32_t i = 0; i < 7u; ++i) rs.k[i] = a + i < n ? (uint32_t)(key[a + i] >> 32) : 0xffffffffu;
+            }
+            {
+                uint32_t a = 0, z = n;
+                while (a < z) {
+                    const uint32_t mid = a + ((z - a) >> 1);
+                    if ((uint64_t)skey[mid] < edge)
+                        a = mid + 1;
+                    else
+                        z = mid;
+                }
+                rt.rank = a;
+#pragma unroll
+                for (uint32_t i = 0; i < 7u; ++i) rt.k[i] = a + i < n ? skey[a + i] : 0xffffffffu;
+            }
+            bk_start[2u * (cell0 + b)] = rs;
+            bk_stop[2u * (cell0 + b)] = rt;
+        }
+    }
+}
+
+template <uint32_t CAP, uint32_t T>
+hipError_t index_build_launch(gams_gpu_t *h, hipStream_t st, const uint32_t *off32, uint32_t n_groups, const uint32_t *starts,
+                              const uint32_t *stops, gams_index_t *ix) {
+    const size_t lds = (size_t)CAP * (8 + 4 + 2) + 96 * 4;
+    auto kern = index_build_kernel<CAP, T>;
+    hipError_t e = gams_lds_attr(h, reinterpret_cast<const void *>(kern), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(n_groups), dim3(T), lds, st, off32, n_groups, starts, stops, ix->d_lstart, ix->d_lrec,
+                       ix->d_stops, ix->d_groups, ix->d_cgroups, ix->d_dir_start, ix->d_bk_start, ix->d_bk_stop);
+    return hipGetLastError();
+}
+
 // Host side of the directory: keys[0..n) ascending (already biased); dir gets nb+1 <= n+1 entries.
 KeyDir build_dir(const uint32_t *keys, uint32_t n, uint32_t *dir) {
     KeyDir d{0u, 0u, 0u, 0u};
@@ -777,11 +1073,29 @@ int gams_index_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
     for (uint32_t g = 0; g <= n_groups; ++g) off32[g] = (uint32_t)group_off[g];
     if ((e = hipMemcpyAsync(d_off32, off32.data(), off32.size() * 4, hipMemcpyHostToDevice, st)) != hipSuccess)
         return fail(e, "copy offsets");
+    uint32_t max_n = 0;
+    for (uint32_t g = 0; g < n_groups; ++g) max_n = std::max(max_n, off32[g + 1] - off32[g]);
     if (m) {
         if ((e = hipMemcpyAsync(d_starts_in, starts, m * 4, hipMemcpyHostToDevice, st)) != hipSuccess)
             return fail(e, "copy starts");
         if ((e = hipMemcpyAsync(d_stops_in, stops, m * 4, hipMemcpyHostToDevice, st)) != hipSuccess)
             return fail(e, "copy stops");
+    }
+    if (n_groups && max_n <= kBuildCap) {
+        // every group fits a workgroup: sort and every derived table in one kernel, one workgroup per group
+        if (max_n <= 256)
+            e = index_build_launch<256, 128>(h, st, d_off32, n_groups, d_starts_in, d_stops_in, ix);
+        else if (max_n <= 1024)
+            e = index_build_launch<1024, 512>(h, st, d_off32, n_groups, d_starts_in, d_stops_in, ix);
+        else if (max_n <= 2048)
+            e = index_build_launch<2048, 1024>(h, st, d_off32, n_groups, d_starts_in, d_stops_in, ix);
+        else if (max_n <= 4096)
+            e = index_build_launch<4096, 1024>(h, st, d_off32, n_groups, d_starts_in, d_stops_in, ix);
+        else
+            e = index_build_launch<8192, 1024>(h, st, d_off32, n_groups, d_starts_in, d_stops_in, ix);
+        if (e != hipSuccess) return fail(e, "group build");
+    } else if (m) {
+        // a group beyond the workgroup's LDS: the library's segmented radix sort + the table kernels
         const unsigned blocks = (unsigned)((m + 255) / 256);
         hipLaunchKernelGGL(index_pack_kernel, dim3(blocks), dim3(256), 0, st, d_starts_in, d_stops_in, m, d_key_in,
                            d_val_in);
@@ -805,7 +1119,7 @@ int gams_index_create(gams_gpu_t *h, uint32_t n_groups, const uint64_t *group_of
                            ix->d_lrec);
         if ((e = hipGetLastError()) != hipSuccess) return fail(e, "unpack");
     }
-    if (n_groups) {
+    if (n_groups && max_n > kBuildCap) {
         hipLaunchKernelGGL(index_group_kernel, dim3(n_groups), dim3(64), 0, st, d_off32, n_groups, ix->d_lrec,
                            ix->d_lstart, ix->d_stops, ix->d_groups, ix->d_cgroups);
         if ((e = hipGetLastError()) != hipSuccess) return fail(e, "group records");

@@ -256,3 +256,48 @@ def test_one_interval_group_wider_than_2_31(eng):
         for q in range(qs.size):
             assert cnt[q] == ora.lapper_count(np.array([a], np.uint32), np.array([b], np.uint32), int(qs[q]), int(qe[q]))
     eng.lib.gams_index_destroy(eng.h, ix)
+
+
+@pytest.mark.parametrize("sizes", [(0, 1, 2, 3, 255, 256, 257), (1024, 1025, 7), (2048, 2049), (4096, 4097, 0, 5), (8192, 31),
+                                   (8193, 100), (20000, 3000, 1)])
+def test_index_build_at_every_workgroup_capacity(eng, sizes):
+    """The index build sorts a whole group in one workgroup's LDS (bitonic network, ties broken by the caller's order:
+    the stable intervals.sort() of redis.rs:253,299) up to 8,192 intervals per group and hands larger ones to the
+    library's segmented radix sort: groups of every size around the kernel's capacities, with many equal starts and
+    equal (start, stop) pairs.  count against the closed form on all queries, locate against the oracle's scan
+    (first hit in (start, stop) order; equal pairs are interchangeable)."""
+    rng = np.random.default_rng(sum(sizes))
+    groups = []
+    for n in sizes:
+        st = rng.integers(0, max(4, n // 3 + 1), n).astype(np.uint32) * 7 + 10           # ~3 intervals per start value
+        sp = st + rng.choice([1, 1, 2, 50, 400], n).astype(np.uint32)
+        groups.append((st, sp))
+    off = np.cumsum([0] + list(sizes)).astype(np.uint64)
+    starts = np.concatenate([g[0] for g in groups]).astype(np.uint32)
+    stops = np.concatenate([g[1] for g in groups]).astype(np.uint32)
+    ix = C.c_void_p()
+    eng.check(eng.lib.gams_index_create(eng.h, len(groups), off.ctypes.data, starts.ctypes.data, stops.ctypes.data,
+                                        C.byref(ix)))
+    for g, (st, sp) in enumerate(groups):
+        hi = int(st.max()) + 500 if st.size else 100
+        qs = rng.integers(0, hi, 3000).astype(np.uint32)
+        qe = (qs + rng.choice([1, 2, 9, 300, 5000], qs.size)).astype(np.uint32)
+        qg = np.full(qs.size, g, np.uint32)
+        cnt = np.full(qs.size, -9, np.int32)
+        hit = np.full(qs.size, -9, np.int64)
+        eng.check(eng.lib.gams_gpu_count(eng.h, ix, qg.ctypes.data, qs.ctypes.data, qe.ctypes.data, qs.size, cnt.ctypes.data))
+        eng.check(eng.lib.gams_gpu_locate(eng.h, ix, qg.ctypes.data, qs.ctypes.data, qe.ctypes.data, qs.size, hit.ctypes.data))
+        ss, tt = np.sort(st), np.sort(sp)
+        exp = (np.searchsorted(ss, qe, "left").astype(np.int64) - np.searchsorted(tt, qs.astype(np.uint64) + 1, "left"))
+        assert np.array_equal(cnt, exp), (g, sizes)
+        assert np.array_equal(hit >= 0, exp > 0), (g, sizes)
+        order = np.lexsort((sp, st))
+        ls, lt = st[order], sp[order]
+        for q in range(0, qs.size, 40):
+            k = ora.lapper_find_first(ls, lt, int(qs[q]), int(qe[q]))
+            if k < 0:
+                assert hit[q] == -1
+            else:
+                j = int(hit[q]) - int(off[g])
+                assert 0 <= j < st.size and (st[j], sp[j]) == (ls[k], lt[k]), (g, q)
+    eng.lib.gams_index_destroy(eng.h, ix)
