@@ -22,7 +22,8 @@ def eng():
     e.close()
 
 
-SHARE = int(__import__("os").environ.get("GAMS_C5_SHARE", "8"))      # 1 = the whole of configs[4] (1e8 rg, 1e8 queries)
+SHARE = int(__import__("os").environ.get("GAMS_C5_SHARE", "8"))      # the per-query closed forms on one GPU's share; the whole of
+                                                                      # configs[4] runs below (test_c5_whole_*), unflagged
 
 
 @pytest.fixture(scope="module")
@@ -169,3 +170,135 @@ def test_c5_count_and_anno_over_eight_handles(eng, c5):
     finally:
         for x in engines:
             x.close()
+
+
+# ---- the WHOLE of configs[4] on one GPU, inside the driver's run -------------------------
+# 32 chromosomes x 1e9 bp, 32,000 ctgs, 1e8 stored point ranges, 1e8 queries, 3.2e7 spans.  numpy closed forms over
+# 1e8 queries are what made the GAMS_C5_SHARE=1 run of round 2 take ten minutes, so here every query is checked by
+# something cheap and a stratified tenth of them by the closed form:
+#   all 1e8   `locate`: the O(1) closed form (ctgs tile the chromosome); `locate --count` / `anno`: answers do not
+#             depend on the order the queries arrive in (a run over the queries sorted by (ctg, start) -- the
+#             cache-friendly order -- returns the permuted answers of the arrival-order run), ranges of the values,
+#             and for `locate --count` the double-counting identity on a sample of ctgs: the counts of a ctg's queries
+#             add up to the number of (stored point, query) incidences, computed from the stored points' side;
+#   1e7       every tenth query against the searchsorted closed forms of the tests above;
+#   300/200   the oracle's rust-lapper / anno restatement.
+@pytest.fixture(scope="module")
+def c5_whole():
+    w = synth.c5_workload(share=1)
+    yield w
+    w.clear()
+
+
+def test_c5_whole_locate_count_and_locate(eng, c5_whole):
+    import time
+
+    w = c5_whole
+    t_start = time.perf_counter()
+    nq = w["q_start"].size
+    assert w["n_ctg"] == 32000 and nq == 100_000_000 and w["rg_start"].size == 100_000_000
+    ix = C.c_void_p()
+    eng.check(eng.lib.gams_index_create(eng.h, w["n_ctg"], w["rg_off"].ctypes.data, w["rg_start"].ctypes.data,
+                                        w["rg_stop"].ctypes.data, C.byref(ix)))
+    cnt = np.full(nq, -1, np.int32)
+    eng.check(eng.lib.gams_gpu_count(eng.h, ix, w["q_ctg"].ctypes.data, w["q_start"].ctypes.data,
+                                     w["q_end"].ctypes.data, nq, cnt.ctypes.data))
+    assert int(cnt.min()) >= 0 and 0 < int(cnt.max()) < 40 and (cnt > 0).mean() > 0.5
+    # the same queries sorted by (ctg, start): the permuted answers
+    order = np.argsort((w["q_ctg"].astype(np.uint64) << np.uint64(32)) | w["q_start"].astype(np.uint64), kind="stable")
+    sg, ss, se = (np.ascontiguousarray(w[k][order]) for k in ("q_ctg", "q_start", "q_end"))
+    cnt_sorted = np.full(nq, -1, np.int32)
+    eng.check(eng.lib.gams_gpu_count(eng.h, ix, sg.ctypes.data, ss.ctypes.data, se.ctypes.data, nq, cnt_sorted.ctypes.data))
+    assert np.array_equal(cnt_sorted, cnt[order])
+    eng.lib.gams_index_destroy(eng.h, ix)
+    # double counting on 400 ctgs: sum of the counts of a ctg's queries == incidences counted from the stored points
+    q_lo = np.searchsorted(sg, np.arange(w["n_ctg"] + 1, dtype=np.uint32))
+    rng = np.random.default_rng(11)
+    for c in rng.integers(0, w["n_ctg"], 400):
+        a, b = int(q_lo[c]), int(q_lo[c + 1])
+        pts = w["rg_start"][int(w["rg_off"][c]):int(w["rg_off"][c + 1])].astype(np.int64)
+        qs_c, qe_c = ss[a:b].astype(np.int64), np.sort(se[a:b].astype(np.int64))
+        # a stored point p = [p, p+1) meets the half-open query [qs, qe) iff qs <= p < qe
+        inc = np.searchsorted(qs_c, pts, "right") - np.searchsorted(qe_c, pts, "right")
+        assert int(cnt_sorted[a:b].sum()) == int(inc.sum()), c
+    # every tenth query against the closed form (the stored ranges are points: the sorted stops are the sorted starts + 1)
+    g = np.repeat(np.arange(w["n_ctg"], dtype=np.uint64), np.diff(w["rg_off"]).astype(np.int64))
+    comp_s = (g << np.uint64(32)) | w["rg_start"].astype(np.uint64)
+    del g
+    comp_s.sort()
+    assert np.array_equal(w["rg_stop"], w["rg_start"] + np.uint32(1))
+    sel = slice(3, None, 10)
+    qg = w["q_ctg"][sel].astype(np.uint64) << np.uint64(32)
+    last = np.searchsorted(comp_s, qg | w["q_end"][sel].astype(np.uint64), "left")
+    first = np.searchsorted(comp_s, qg | w["q_start"][sel].astype(np.uint64), "left")     # stops < qs + 1  <=>  starts < qs
+    assert np.array_equal(cnt[sel].astype(np.int64), last.astype(np.int64) - first.astype(np.int64))
+    for q in rng.integers(0, nq, 300):
+        c = int(w["q_ctg"][q])
+        lo, hi = int(w["rg_off"][c]), int(w["rg_off"][c + 1])
+        assert cnt[q] == ora.lapper_count(np.sort(w["rg_start"][lo:hi]), np.sort(w["rg_stop"][lo:hi]),
+                                          int(w["q_start"][q]), int(w["q_end"][q]))
+    del comp_s, cnt, cnt_sorted
+    # locate: which ctg holds each of the 1e8 ranges -- the closed form on every one of them
+    ixc = C.c_void_p()
+    eng.check(eng.lib.gams_index_create(eng.h, w["n_chr"], w["ctg_off"].ctypes.data, w["ctg_start"].ctypes.data,
+                                        w["ctg_stop"].ctypes.data, C.byref(ixc)))
+    hit = np.full(nq, -7, np.int64)
+    eng.check(eng.lib.gams_gpu_locate(eng.h, ixc, w["q_chr"].ctypes.data, w["q_start"].ctypes.data,
+                                      w["q_end"].ctypes.data, nq, hit.ctypes.data))
+    eng.lib.gams_index_destroy(eng.h, ixc)
+    k0 = (w["q_start"].astype(np.int64) - 1) // w["piece"]
+    ok = k0 * w["piece"] + 1 < w["q_end"].astype(np.int64)
+    assert np.array_equal(hit, np.where(ok, w["q_chr"].astype(np.int64) * w["per_chr"] + k0, -1))
+    print(f"configs[4] whole, count + locate: {time.perf_counter() - t_start:.0f} s")
+
+
+def test_c5_whole_anno(eng, c5_whole):
+    w = c5_whole
+    nq = w["q_start"].size
+    assert w["sp_lo"].size == 32_000_000
+    sp = C.c_void_p()
+    eng.check(eng.lib.gams_spans_create(eng.h, w["n_chr"], w["sp_off"].ctypes.data, w["sp_lo"].ctypes.data,
+                                        w["sp_hi"].ctypes.data, C.byref(sp)))
+    s = w["q_start"].astype(np.int32)
+    e = w["q_end"].astype(np.int32)
+    cl = (((s.astype(np.int64) - 1) // w["piece"]) * w["piece"] + 1).astype(np.int32)
+    ch = (cl + (w["piece"] - 1)).astype(np.int32)
+    prop = np.full(nq, -1.0, np.float32)
+    eng.check(eng.lib.gams_gpu_cover(eng.h, sp, w["q_chr"].ctypes.data, cl.ctypes.data, ch.ctypes.data,
+                                     s.ctypes.data, e.ctypes.data, nq, prop.ctypes.data))
+    assert float(prop.min()) >= 0.0 and float(prop.max()) <= 1.0 and 0.3 < float(prop[::7].mean()) < 0.7
+    # another arrival order (reversed): the permuted answers
+    rev = [np.ascontiguousarray(x[::-1]) for x in (w["q_chr"], cl, ch, s, e)]
+    prop_r = np.full(nq, -1.0, np.float32)
+    eng.check(eng.lib.gams_gpu_cover(eng.h, sp, rev[0].ctypes.data, rev[1].ctypes.data, rev[2].ctypes.data,
+                                     rev[3].ctypes.data, rev[4].ctypes.data, nq, prop_r.ctypes.data))
+    eng.lib.gams_spans_destroy(eng.h, sp)
+    assert np.array_equal(prop_r[::-1], prop)
+    del rev, prop_r
+    # every tenth line against the closed form (the spans of a chromosome are sorted: chr << 32 | lo ascends)
+    n_sp = int(w["sp_off"][1])
+    lo = w["sp_lo"].astype(np.int64)
+    hi = w["sp_hi"].astype(np.int64)
+    chr_of = np.repeat(np.arange(w["n_chr"], dtype=np.int64), n_sp)
+    comp_lo = (chr_of << 32) | lo
+    cum = np.concatenate([[0], np.cumsum(hi - lo + 1)])
+
+    def covered(c, x):
+        i = np.searchsorted(comp_lo, (c << 32) | x, "right")
+        last = np.maximum(i - 1, 0)
+        over = np.where((i > 0) & (chr_of[last] == c), np.maximum(hi[last] - x, 0), 0)
+        return cum[i] - over
+
+    sel = slice(5, None, 10)
+    c = w["q_chr"][sel].astype(np.int64)
+    L = np.maximum(s[sel].astype(np.int64), cl[sel])
+    H = np.minimum(e[sel].astype(np.int64), ch[sel])
+    card = np.where(H >= L, covered(c, H) - covered(c, L - 1), 0)
+    exp = card.astype(np.int32).astype(np.float32) / (e[sel].astype(np.int64) - s[sel] + 1).astype(np.int32).astype(np.float32)
+    assert np.array_equal(prop[sel], exp)
+    rng = np.random.default_rng(13)
+    for q in rng.integers(0, nq, 200):
+        k = int(w["q_chr"][q])
+        a, b = int(w["sp_off"][k]), int(w["sp_off"][k + 1])
+        got = ora.anno_prop(w["sp_lo"][a:b], w["sp_hi"][a:b], int(cl[q]), int(ch[q]), int(s[q]), int(e[q]))
+        assert np.float32(got) == prop[q]
