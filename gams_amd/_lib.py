@@ -70,6 +70,9 @@ PROTOTYPES = {
     "gams_wave_plan_set_pipelined": (C.c_int, [_VP, _VP, C.c_int]),
     "gams_wave_run": (C.c_int, [_VP, _VP]),
     "gams_wave_peaks": (C.c_int, [_VP, _VP, _PP, C.POINTER(C.c_uint64)]),
+    "gams_wave_rows_setup": (C.c_int, [_VP, _VP, C.POINTER(C.c_char_p), _VP, C.c_float]),
+    "gams_wave_rows_begin": (C.c_int, [_VP, _VP]),
+    "gams_wave_rows_end": (C.c_int, [_VP, _VP, _PP, C.POINTER(C.c_uint64), _PP]),
     "gams_wave_dense": (C.c_int, [_VP, _VP, C.c_uint32, _VP, _VP]),
     "gams_wave_plan_set_tile": (C.c_int, [_VP, _VP, C.c_uint32]),
     "gams_wave_exact_count": (C.c_int, [_VP, _VP, C.POINTER(C.c_uint64)]),

@@ -41,11 +41,38 @@
 
 #include "wave_kernels.hpp"
 #include "wave_repair.hpp"
+#include "wave_rows.hpp"
+
+#include <charconv>
 
 
 // =============================================================================
 // host side
 // =============================================================================
+// gams_wave_rows_*: the plan's TSV rows made on the device (wave_rows.hpp)
+struct WaveRows {
+    uint32_t dmax = 0, max_name = 0;
+    uint8_t *arena = nullptr;                 // RowCtg[n_ctg] | names | gc text table | ctg_off[n_ctg + 1] | out_sizes[4]
+    size_t arena_bytes = 0;
+    RowCtg *d_ctgs = nullptr;
+    char *d_names = nullptr;
+    uint8_t *d_gctab = nullptr;
+    unsigned long long *d_ctg_off = nullptr, *d_sizes = nullptr;
+    uint8_t *tmp = nullptr;                   // per-record and per-block tables, room for `cap` records
+    size_t tmp_bytes = 0;
+    uint64_t cap = 0;
+    char *d_text = nullptr;
+    size_t d_text_bytes = 0;
+    char *h_text = nullptr;                   // page-locked
+    size_t h_text_bytes = 0;
+    unsigned long long *h_words = nullptr;    // page-locked: [0] records, [1] text bytes, [2] peaks (offsets kernel), [3] fullest tile, [4..] ctg_off
+    size_t h_words_bytes = 0;
+    uint64_t copied = 0;                      // text bytes the last begin() already sent to the host
+    uint64_t last_bytes = 0;                  // text bytes of the previous pass (sizes the speculative copy)
+    hipEvent_t done = nullptr;
+    bool begun = false;
+};
+
 struct Launcher;
 struct gams_wave_plan {
     gams_seqset_t *set = nullptr;
@@ -122,10 +149,12 @@ struct gams_wave_plan {
     bool attr_set = false;        // dynamic-LDS attribute applied for the current geometry
     float g0 = 0, g1 = 0, g2 = 0, g3 = 0;
     float sq[6] = {0, 0, 0, 0, 0, 0};   // aA, aB, gA0, gA1, gB0, gB1 (wave_squared_band)
+    WaveRows *rows = nullptr;           // gams_wave_rows_setup
     float guard_safety = 1.5f;          // gams_wave_plan_set_guard
     bool guard_exact = false;           // every window through the exact path
 };
 static void wave_launcher_stop(gams_wave_plan_t *p);
+
 
 namespace {
 
@@ -644,6 +673,17 @@ void gams_wave_plan_destroy(gams_gpu_t *h, gams_wave_plan_t *p) {
         for (uint32_t k = 0; k < p->depth; ++k)
             if (wave_stream(h, p, k)) (void)hipStreamSynchronize(wave_stream(h, p, k));
         if (h->readback) (void)hipStreamSynchronize(h->readback);
+    }
+    if (p->rows) {
+        WaveRows *r = p->rows;
+        gams_pool_free(h, false, r->arena, r->arena_bytes);
+        gams_pool_free(h, false, r->tmp, r->tmp_bytes);
+        gams_pool_free(h, false, r->d_text, r->d_text_bytes);
+        gams_pool_free(h, true, r->h_text, r->h_text_bytes);
+        gams_pool_free(h, true, r->h_words, r->h_words_bytes);
+        if (r->done) (void)hipEventDestroy(r->done);
+        delete r;
+        p->rows = nullptr;
     }
     gams_pool_free(h, false, p->arena_fixed, p->arena_fixed_bytes);
     gams_pool_free(h, false, p->arena_geom, p->arena_geom_bytes);
@@ -1280,6 +1320,324 @@ int gams_wave_peaks(gams_gpu_t *h, gams_wave_plan_t *p, const gams_peak_t **peak
         return GAMS_OK;
     }
     return gams_fail(h, GAMS_EHIP, "wave_peaks: peak buffer overflow persisted");
+}
+
+// ---- rows as text ---------------------------------------------------------------------------------
+}  // extern "C"
+namespace {
+// Rust's `{}` of an f32: the shortest digits that round-trip, positional notation (what wave.rs:196 prints)
+std::string rows_fmt_f32(float v) {
+    if (v == 0.0f) return "0";
+    char buf[64];
+    auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::scientific);
+    std::string sci(buf, r.ptr), digits, out;             // d[.ddd]e[+-]XX  (v > 0 here)
+    size_t i = 0;
+    for (; i < sci.size() && sci[i] != 'e'; ++i)
+        if (sci[i] != '.') digits += sci[i];
+    const int ex = std::atoi(sci.c_str() + i + 1), nd = (int)digits.size();
+    if (ex >= 0) {
+        for (int k = 0; k <= ex; ++k) out += k < nd ? digits[k] : '0';
+        if (nd > ex + 1) {
+            out += '.';
+            out.append(digits, ex + 1, std::string::npos);
+        }
+    } else {
+        out += "0.";
+        out.append((size_t)(-ex - 1), '0');
+        out += digits;
+    }
+    return out;
+}
+
+struct RowTables {
+    uint8_t *flags;
+    int2 *headpos, *blk_head;
+    uint32_t *tailwin, *len, *blk_len;
+    unsigned long long *blk_off;
+    uint32_t nb_cap;
+    size_t bytes;
+};
+RowTables rows_carve(uint8_t *base, uint64_t cap) {
+    const uint32_t nb = (uint32_t)((cap + kRowsBlock - 1) / kRowsBlock);
+    size_t o = 0;
+    auto take = [&](size_t b) {
+        uint8_t *q = base ? base + o : nullptr;
+        o += wave_align256(b);
+        return q;
+    };
+    RowTables t{};
+    t.headpos = reinterpret_cast<int2 *>(take(cap * 8));
+    t.tailwin = reinterpret_cast<uint32_t *>(take(cap * 4));
+    t.len = reinterpret_cast<uint32_t *>(take(cap * 4));
+    t.flags = take(cap);
+    t.blk_head = reinterpret_cast<int2 *>(take((size_t)nb * 8));
+    t.blk_len = reinterpret_cast<uint32_t *>(take((size_t)nb * 4));
+    t.blk_off = reinterpret_cast<unsigned long long *>(take(((size_t)nb + 2) * 8));
+    t.nb_cap = nb;
+    t.bytes = o;
+    return t;
+}
+
+// queue everything of one rows pass on the readback stream, behind the run the readers look at
+int rows_queue(gams_gpu_t *h, gams_wave_plan_t *p) {
+    WaveRows *r = p->rows;
+    const size_t nt = p->tiles.size();
+    unsigned long long *const d_totals = p->d_tile_off + nt;
+    gams_wave_plan::Way &w = wave_read_way(p);
+    hipStream_t st = h->readback;
+    if (p->pipelined && w.done) {
+        GAMS_HIP(h, hipStreamWaitEvent(st, w.done, 0));
+    } else {
+        if (!w.ran_ev) GAMS_HIP(h, hipEventCreateWithFlags(&w.ran_ev, hipEventDisableTiming));
+        GAMS_HIP(h, hipEventRecord(w.ran_ev, wave_stream(h, p, wave_read_way_index(p))));
+        GAMS_HIP(h, hipStreamWaitEvent(st, w.ran_ev, 0));
+    }
+    if (!p->d_dense) {
+        const uint64_t want = p->total_windows / 16 + 4096;
+        GAMS_HIP(h, gams_pool_alloc(h, false, want * sizeof(gams_peak_t), reinterpret_cast<void **>(&p->d_dense),
+                                    &p->d_dense_bytes));
+        p->dense_cap = p->d_dense_bytes / sizeof(gams_peak_t);
+    }
+    const uint64_t cap = std::min<uint64_t>(p->dense_cap, 0x7FFFFF00ull);
+    if (r->cap < cap) {
+        gams_pool_free(h, false, r->tmp, r->tmp_bytes);
+        r->tmp = nullptr;
+        r->cap = 0;
+        GAMS_HIP(h, gams_pool_alloc(h, false, rows_carve(nullptr, cap).bytes, reinterpret_cast<void **>(&r->tmp), &r->tmp_bytes));
+        r->cap = cap;
+    }
+    const uint64_t want_text = std::max<uint64_t>(r->cap * ((uint64_t)r->max_name + 44u), 1u << 20);
+    if (r->d_text_bytes < want_text) {
+        gams_pool_free(h, false, r->d_text, r->d_text_bytes);
+        r->d_text = nullptr;
+        r->d_text_bytes = 0;
+        GAMS_HIP(h, gams_pool_alloc(h, false, want_text, reinterpret_cast<void **>(&r->d_text), &r->d_text_bytes));
+    }
+    const RowTables t = rows_carve(r->tmp, r->cap);
+    hipLaunchKernelGGL(wave_offsets_kernel, dim3(1), dim3(1024), 0, st, w.d_tile_cnt, (uint32_t)nt, p->d_tile_off, d_totals);
+    hipLaunchKernelGGL(wave_gather_kernel, dim3((unsigned)nt), dim3(64), 0, st, w.d_peaks, p->tile_cap, w.d_tile_cnt,
+                       p->d_tile_off, p->d_dense, (unsigned long long)p->dense_cap);
+    GAMS_HIP(h, hipGetLastError());
+    const uint32_t n_ctg = p->set->n_ctg;
+    GAMS_HIP(h, hipMemsetAsync(r->d_ctg_off, 0xFF, ((size_t)n_ctg + 1) * 8, st));
+    RowArgs a{};
+    a.rec = p->d_dense;
+    a.n_rec = d_totals;
+    a.cap = std::min<uint64_t>(r->cap, p->dense_cap);
+    a.tile_cap = p->tile_cap;
+    a.ctgs = r->d_ctgs;
+    a.names = r->d_names;
+    a.gctab = r->d_gctab;
+    a.size = (uint32_t)p->prm.size;
+    a.step = (uint32_t)p->prm.step;
+    a.dmax = r->dmax;
+    a.flags = t.flags;
+    a.headpos = t.headpos;
+    a.blk_head = t.blk_head;
+    a.tailwin = t.tailwin;
+    a.len = t.len;
+    a.blk_len = t.blk_len;
+    a.blk_off = t.blk_off;
+    a.nb_cap = t.nb_cap;
+    a.text = r->d_text;
+    a.text_cap = r->d_text_bytes;
+    a.ctg_off = r->d_ctg_off;
+    a.out_sizes = r->d_sizes;
+    const unsigned nb = t.nb_cap;
+    hipLaunchKernelGGL(rows_link_kernel, dim3(nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(rows_heads_kernel, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(rows_tail_kernel, dim3((unsigned)((r->cap + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(rows_len_kernel, dim3(nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(wave_offsets_kernel, dim3(1), dim3(1024), 0, st, t.blk_len, nb, t.blk_off, t.blk_off + nb);
+    hipLaunchKernelGGL(rows_write_kernel, dim3(nb), dim3(256), 0, st, a);
+    GAMS_HIP(h, hipGetLastError());
+    // sizes, per-ctg offsets and -- sized by the previous pass -- the text itself go to the host behind the kernels
+    GAMS_HIP(h, hipMemcpyAsync(r->h_words, r->d_sizes, 2 * 8, hipMemcpyDeviceToHost, st));
+    GAMS_HIP(h, hipMemcpyAsync(r->h_words + 2, d_totals, 2 * 8, hipMemcpyDeviceToHost, st));
+    GAMS_HIP(h, hipMemcpyAsync(r->h_words + 4, r->d_ctg_off, ((size_t)n_ctg + 1) * 8, hipMemcpyDeviceToHost, st));
+    r->copied = 0;
+    if (r->last_bytes) {
+        const uint64_t guess = std::min<uint64_t>(r->d_text_bytes, r->last_bytes + r->last_bytes / 8 + 4096);
+        if (r->h_text_bytes < guess) {
+            gams_pool_free(h, true, r->h_text, r->h_text_bytes);
+            r->h_text = nullptr;
+            r->h_text_bytes = 0;
+            GAMS_HIP(h, gams_pool_alloc(h, true, guess, reinterpret_cast<void **>(&r->h_text), &r->h_text_bytes));
+        }
+        GAMS_HIP(h, hipMemcpyAsync(r->h_text, r->d_text, guess, hipMemcpyDeviceToHost, st));
+        r->copied = guess;
+    }
+    if (!r->done) GAMS_HIP(h, hipEventCreateWithFlags(&r->done, hipEventDisableTiming));
+    GAMS_HIP(h, hipEventRecord(r->done, st));
+    r->begun = true;
+    return GAMS_OK;
+}
+}  // namespace
+extern "C" {
+
+int gams_wave_rows_setup(gams_gpu_t *h, gams_wave_plan_t *p, const char *const *chr, const int32_t *chr_start,
+                         float coverage) {
+    if (!h || !p || (p->set->n_ctg && (!chr || !chr_start))) return gams_fail(h, GAMS_EINVAL, "wave_rows_setup: null argument");
+    if (!(p->flags & GAMS_WAVE_PEAKS)) return gams_fail(h, GAMS_ESTATE, "wave_rows_setup: plan has no PEAKS output");
+    const gams_wave_params_t &q = p->prm;
+    // merge_ints (wave.rs:217-252) links windows i < j iff they intersect and size / |intersection| >= coverage
+    // (both ratios are that one: all windows have one size).  The device makes rows when every intersecting
+    // pair links, i.e. when the smallest possible ratio -- at distance 1 -- already passes.
+    const int64_t dmax = ((int64_t)q.size + q.step - 1) / q.step - 1;
+    if (dmax >= 1) {
+        const float inter = (float)(int32_t)(q.size - q.step);
+        if (!((float)q.size / inter >= coverage))
+            return gams_fail(h, GAMS_EUNSUPPORTED,
+                             "wave_rows_setup: this --coverage links only some of the overlapping windows; merge the "
+                             "peaks on the host (gams_wave_peaks)");
+    }
+    const uint32_t n_ctg = p->set->n_ctg;
+    for (uint32_t c = 0; c < n_ctg; ++c) {
+        if (!chr[c]) return gams_fail(h, GAMS_EINVAL, "wave_rows_setup: null chromosome name");
+        if (chr_start[c] < 0 || (int64_t)chr_start[c] + p->ctgs[c].len >= 0x7FFFFFFFll)
+            return gams_fail(h, GAMS_EINVAL, "wave_rows_setup: chromosome coordinates must be in [0, 2^31)");
+    }
+    GAMS_HIP(h, hipSetDevice(h->device));
+    if (p->rows) {                       // set up again (other names / coverage): drop the old tables
+        GAMS_HIP(h, hipStreamSynchronize(h->readback));
+        WaveRows *r = p->rows;
+        gams_pool_free(h, false, r->arena, r->arena_bytes);
+        gams_pool_free(h, true, r->h_words, r->h_words_bytes);
+        r->arena = nullptr;
+        r->h_words = nullptr;
+    } else {
+        p->rows = new WaveRows();
+    }
+    WaveRows *r = p->rows;
+    r->dmax = (uint32_t)dmax;
+    r->begun = false;
+    // names (one copy per distinct pointer is not worth the bookkeeping: a few bytes per ctg), gc text table
+    std::vector<RowCtg> rc(std::max<uint32_t>(n_ctg, 1));
+    std::string blob;
+    r->max_name = 0;
+    for (uint32_t c = 0; c < n_ctg; ++c) {
+        const size_t len = std::strlen(chr[c]);
+        size_t at = blob.find(chr[c]);   // ctgs of one chromosome share its name
+        if (at == std::string::npos || (len == 0)) {
+            at = blob.size();
+            blob += chr[c];
+        }
+        rc[c] = RowCtg{(uint32_t)at, (uint32_t)len, chr_start[c], 0u};
+        r->max_name = std::max<uint32_t>(r->max_name, (uint32_t)len);
+    }
+    std::vector<uint8_t> gct(((size_t)q.size + 1) * kGcStride, 0);
+    for (int32_t k = 0; k <= q.size; ++k) {
+        const std::string t = rows_fmt_f32((float)k / (float)q.size);     // gc_content as wave.rs prints it
+        if (t.size() > kGcStride - 1) return gams_fail(h, GAMS_EUNSUPPORTED, "wave_rows_setup: gc_content text too long");
+        gct[(size_t)k * kGcStride] = (uint8_t)t.size();
+        std::memcpy(&gct[(size_t)k * kGcStride + 1], t.data(), t.size());
+    }
+    const size_t b_ctgs = wave_align256(rc.size() * sizeof(RowCtg)), b_names = wave_align256(std::max<size_t>(blob.size(), 1)),
+                 b_gc = wave_align256(gct.size()), b_off = wave_align256(((size_t)n_ctg + 1) * 8), b_sz = 256;
+    GAMS_HIP(h, gams_pool_alloc(h, false, b_ctgs + b_names + b_gc + b_off + b_sz, reinterpret_cast<void **>(&r->arena),
+                                &r->arena_bytes));
+    r->d_ctgs = reinterpret_cast<RowCtg *>(r->arena);
+    r->d_names = reinterpret_cast<char *>(r->arena + b_ctgs);
+    r->d_gctab = r->arena + b_ctgs + b_names;
+    r->d_ctg_off = reinterpret_cast<unsigned long long *>(r->arena + b_ctgs + b_names + b_gc);
+    r->d_sizes = reinterpret_cast<unsigned long long *>(r->arena + b_ctgs + b_names + b_gc + b_off);
+    GAMS_HIP(h, hipMemcpy(r->d_ctgs, rc.data(), rc.size() * sizeof(RowCtg), hipMemcpyHostToDevice));
+    if (!blob.empty()) GAMS_HIP(h, hipMemcpy(r->d_names, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    GAMS_HIP(h, hipMemcpy(r->d_gctab, gct.data(), gct.size(), hipMemcpyHostToDevice));
+    GAMS_HIP(h, gams_pool_alloc(h, true, ((size_t)n_ctg + 1 + 4) * 8, reinterpret_cast<void **>(&r->h_words), &r->h_words_bytes));
+    return GAMS_OK;
+}
+
+int gams_wave_rows_begin(gams_gpu_t *h, gams_wave_plan_t *p) {
+    if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_rows_begin: null argument");
+    if (!p->rows) return gams_fail(h, GAMS_ESTATE, "wave_rows_begin: call gams_wave_rows_setup first");
+    if (!p->ran) return gams_fail(h, GAMS_ESTATE, "wave_rows_begin: no run to read");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    if (p->tiles.empty()) {
+        p->rows->begun = true;
+        return GAMS_OK;
+    }
+    return rows_queue(h, p);
+}
+
+int gams_wave_rows_end(gams_gpu_t *h, gams_wave_plan_t *p, const char **text, uint64_t *text_bytes,
+                       const uint64_t **ctg_off) {
+    if (!h || !p || !text || !text_bytes) return gams_fail(h, GAMS_EINVAL, "wave_rows_end: null argument");
+    if (!p->rows || !p->rows->begun) return gams_fail(h, GAMS_ESTATE, "wave_rows_end: no gams_wave_rows_begin to finish");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    WaveRows *r = p->rows;
+    const uint32_t n_ctg = p->set->n_ctg;
+    r->begun = false;
+    if (p->tiles.empty()) {
+        for (uint32_t c = 0; c <= n_ctg; ++c) r->h_words[4 + c] = 0;
+        *text = nullptr;
+        *text_bytes = 0;
+        if (ctg_off) *ctg_off = reinterpret_cast<const uint64_t *>(r->h_words + 4);
+        return GAMS_OK;
+    }
+    const size_t nt = p->tiles.size();
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        GAMS_HIP(h, hipEventSynchronize(r->done));
+        const uint64_t n_rec = r->h_words[0], bytes = r->h_words[1], total = r->h_words[2], worst = r->h_words[3];
+        if (worst > p->tw || total > p->total_windows || total > (uint64_t)nt * worst)
+            return gams_fail(h, GAMS_EHIP, "wave_rows: inconsistent peak counts from the device");
+        int rc = GAMS_OK;
+        if (worst > p->tile_cap) {
+            // a tile signalled more windows than its slot holds: larger slots, the passes still held run again
+            // (see gams_wave_peaks), then the rows once more
+            p->tile_cap_req = (uint32_t)std::min<uint64_t>(p->tw, (worst + 15u) & ~(uint64_t)15u);
+            const uint32_t age = p->sel_age;
+            const uint32_t again = (uint32_t)std::min<uint64_t>(p->depth, p->run_idx);
+            rc = wave_sync_ways(h, p);
+            if (rc == GAMS_OK) rc = wave_upload_geometry(h, p);
+            if (rc == GAMS_OK) {
+                p->run_idx -= again;
+                for (uint32_t k = 0; k < again && rc == GAMS_OK; ++k) rc = gams_wave_run(h, p);
+                p->sel_age = age;
+            }
+        } else if (total > p->dense_cap || total > r->cap) {
+            if (total > 0x7FFFFF00ull) return gams_fail(h, GAMS_EUNSUPPORTED, "wave_rows: more than 2^31 peaks in one pass");
+            gams_pool_free(h, false, p->d_dense, p->d_dense_bytes);
+            p->d_dense = nullptr;
+            p->dense_cap = 0;
+            GAMS_HIP(h, gams_pool_alloc(h, false, (total + total / 4 + 1024) * sizeof(gams_peak_t),
+                                        reinterpret_cast<void **>(&p->d_dense), &p->d_dense_bytes));
+            p->dense_cap = p->d_dense_bytes / sizeof(gams_peak_t);
+        } else if (bytes > r->d_text_bytes) {
+            return gams_fail(h, GAMS_EHIP, "wave_rows: text beyond its bound");
+        } else {
+            (void)n_rec;
+            if (bytes > r->copied) {
+                // the speculative copy fell short (the first pass, or more text than last time): the rest now
+                if (r->h_text_bytes < bytes) {
+                    char *nt_ = nullptr;
+                    size_t nb_ = 0;
+                    GAMS_HIP(h, gams_pool_alloc(h, true, bytes + bytes / 4 + 4096, reinterpret_cast<void **>(&nt_), &nb_));
+                    if (r->copied) std::memcpy(nt_, r->h_text, r->copied);
+                    gams_pool_free(h, true, r->h_text, r->h_text_bytes);
+                    r->h_text = nt_;
+                    r->h_text_bytes = nb_;
+                }
+                GAMS_HIP(h, hipMemcpyAsync(r->h_text + r->copied, r->d_text + r->copied, bytes - r->copied,
+                                           hipMemcpyDeviceToHost, h->readback));
+                GAMS_HIP(h, hipStreamSynchronize(h->readback));
+            }
+            r->last_bytes = bytes;
+            // ctgs without a row begin where the next ctg's rows begin
+            unsigned long long *off = r->h_words + 4;
+            off[n_ctg] = bytes;
+            for (uint32_t c = n_ctg; c-- > 0;)
+                if (off[c] == ~0ull) off[c] = off[c + 1];
+            *text = bytes ? r->h_text : nullptr;
+            *text_bytes = bytes;
+            if (ctg_off) *ctg_off = reinterpret_cast<const uint64_t *>(off);
+            return GAMS_OK;
+        }
+        if (rc != GAMS_OK) return rc;
+        rc = rows_queue(h, p);
+        if (rc != GAMS_OK) return rc;
+    }
+    return gams_fail(h, GAMS_EHIP, "wave_rows: buffers kept overflowing");
 }
 
 int gams_wave_dense(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t i, uint32_t *gc_count, int8_t *signal) {

@@ -155,6 +155,27 @@ class WavePlan:
         self.eng.check(self.eng.lib.gams_wave_peaks(self.eng.h, self.p, C.byref(ptr), C.byref(n)))
         return int(n.value)
 
+    def rows_setup(self, chr_names, chr_starts, coverage=0.2):
+        """device-made TSV rows (gams_wave_rows_*): chromosome name / first coordinate per ctg, --coverage"""
+        n = len(chr_names)
+        self._row_names = (C.c_char_p * max(n, 1))(*[x.encode() for x in chr_names])
+        self._row_starts = np.asarray(chr_starts, np.int32)
+        self.eng.check(self.eng.lib.gams_wave_rows_setup(self.eng.h, self.p, self._row_names, self._row_starts.ctypes.data,
+                                                         coverage))
+
+    def rows_begin(self):
+        self.eng.check(self.eng.lib.gams_wave_rows_begin(self.eng.h, self.p))
+
+    def rows_end(self, copy=True):
+        """-> (text bytes, ctg offsets); copy=False: only the byte count (the text stays in plan-owned memory)"""
+        txt, n, off = C.c_void_p(), C.c_uint64(), C.c_void_p()
+        self.eng.check(self.eng.lib.gams_wave_rows_end(self.eng.h, self.p, C.byref(txt), C.byref(n), C.byref(off)))
+        if not copy:
+            return int(n.value)
+        n_ctg = len(self._row_names) if self._row_starts.size else 0
+        offs = np.frombuffer((C.c_uint64 * (n_ctg + 1)).from_address(off.value), np.uint64).copy()
+        return (C.string_at(txt.value, n.value) if n.value else b""), offs
+
     def set_taper_shape(self, pct4, pct8=None):
         """size of the tapered launch's two tails in % of a round of workgroup slots (default 25 / 50)"""
         if pct8 is None:                      # tools/ab_plans.py passes one integer: pct4 * 1000 + pct8

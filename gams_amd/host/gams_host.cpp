@@ -301,14 +301,31 @@ struct WaveJob {
         t_mark = t;
     }
     void plan_and_run();
+    bool device_rows = false;      // the rows come as text from the device (gams_wave_rows_*): coverage links every overlap
 };
 
 void WaveJob::plan_and_run() {
     gams_wave_params_t prm{a.size, a.step, a.lag, a.threshold, a.influence};
     check(h, gams_wave_plan_create(h, sg.s, &prm, a.signal ? GAMS_WAVE_DENSE : GAMS_WAVE_PEAKS, &pg.p));
     check(h, gams_wave_plan_set_pipelined(h, pg.p, 1));   // finish() waits for this job, not the stream
+    if (!a.signal) {
+        // merged rows on the device when --coverage links every overlap (every value up to 1; the default is 0.2);
+        // otherwise the peaks come back and merge_ints runs here
+        std::vector<const char *> chr(ctgs.size());
+        std::vector<int32_t> cs(ctgs.size());
+        for (size_t c = 0; c < ctgs.size(); ++c) {
+            chr[c] = ctgs[c].chr_id.c_str();
+            cs[c] = ctgs[c].chr_start;
+        }
+        const int rc = gams_wave_rows_setup(h, pg.p, chr.data(), cs.data(), a.coverage);
+        if (rc == GAMS_OK)
+            device_rows = true;
+        else if (rc != GAMS_EUNSUPPORTED)
+            check(h, rc);
+    }
     mark(&WaveStages::plan_ms);
     check(h, gams_wave_run(h, pg.p));
+    if (device_rows) check(h, gams_wave_rows_begin(h, pg.p));   // packing, merging, formatting and the copy queue behind the pass
     mark(&WaveStages::kernel_ms);
 }
 
@@ -424,6 +441,17 @@ std::vector<std::string> WaveJob::finish() {
                 o += '\n';
             }
         });
+        return out;
+    }
+    if (device_rows) {
+        const char *text = nullptr;
+        uint64_t bytes = 0;
+        const uint64_t *off = nullptr;
+        check(h, gams_wave_rows_end(h, pg.p, &text, &bytes, &off));
+        mark(&WaveStages::peaks_ms);
+        for (uint32_t c = 0; c < n; ++c) out[c].assign(text + off[c], text + off[c + 1]);
+        if (st) st->peaks = bytes;          // (text bytes fetched: the peak records stay on the device)
+        mark(&WaveStages::format_ms);
         return out;
     }
     const gams_peak_t *pk = nullptr;

@@ -161,6 +161,22 @@ int gams_wave_plan_set_pipelined(gams_gpu_t *h, gams_wave_plan_t *p, int enable)
  * *peaks points into plan-owned host memory, valid until the next run. */
 int gams_wave_peaks(gams_gpu_t *h, gams_wave_plan_t *p,
                     const gams_peak_t **peaks, uint64_t *n_peaks);
+/* The rows of `gams wave` as TSV text, made on the device (wave.rs:157-252: crests and troughs separately,
+ * overlapping windows merged into "{chr}(+):{min}-{max}", every row "...\t{gc_content}\t{signal}\n" in window
+ * order, gc_content printed like Rust's `{}` of an f32) -- what the host otherwise derives from gams_wave_peaks.
+ * setup: once per plan; chr[i] / chr_start[i] = chromosome name and first chromosome coordinate of ctg i
+ *   (chr_id, chr_start of its Ctg record); coverage = --coverage.  GAMS_EUNSUPPORTED when that coverage links
+ *   only some of the overlapping windows (> size / (size - step): merge gams_wave_peaks on the host then).
+ * begin: queue the packing of the selected run's peaks, the rows and their copy to the host behind that run;
+ *   returns at once, so several plans can have their rows in flight while later passes compute.
+ * end: wait for this plan's rows.  *text (text_bytes bytes, no header line, no terminating NUL) and *ctg_off
+ *   (n_ctg + 1 offsets: the rows of ctg i are text[ctg_off[i] .. ctg_off[i+1])) point into plan-owned
+ *   page-locked memory, valid until the plan's next gams_wave_rows_begin. */
+int gams_wave_rows_setup(gams_gpu_t *h, gams_wave_plan_t *p, const char *const *chr,
+                         const int32_t *chr_start, float coverage);
+int gams_wave_rows_begin(gams_gpu_t *h, gams_wave_plan_t *p);
+int gams_wave_rows_end(gams_gpu_t *h, gams_wave_plan_t *p, const char **text, uint64_t *text_bytes,
+                       const uint64_t **ctg_off);
 /* Wait for the last run and copy ctg i's dense rows (either pointer may be NULL). */
 int gams_wave_dense(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t i,
                     uint32_t *gc_count, int8_t *signal);

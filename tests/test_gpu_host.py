@@ -566,3 +566,100 @@ def test_wave_multi_one_handle_per_device(eng, s288c):
     finally:
         for e in engines:
             e.close()
+
+
+# ---- wave rows made on the device (gams_wave_rows_*) --------------------------------------------------------
+def _host_rows(ctgs, peaks, size, step, coverage):
+    """the host layer's merge + formatting over peak records (the path the device rows replace), per ctg"""
+    out = []
+    for c, ctg in enumerate(ctgs):
+        mine = peaks[peaks["ctg"] == c]
+        rows = []
+        cmin = np.zeros(mine.size, np.int64)
+        cmax = np.zeros(mine.size, np.int64)
+        merged = np.zeros(mine.size, np.uint8)
+        for sgn in (1, -1):
+            sel = np.flatnonzero(mine["signal"] == sgn)
+            if sel.size:
+                a, b, m = host.merge_windows(mine["window"][sel], ctg["chr_start"], size, step, coverage)
+                cmin[sel], cmax[sel], merged[sel] = a, b, m
+        for i in range(mine.size):
+            s = ctg["chr_start"] + int(mine["window"][i]) * step
+            e = s + size - 1
+            gc = host.fmt_f32(np.float32(mine["gc_count"][i]) / np.float32(size))
+            if merged[i]:
+                if s != cmin[i]:
+                    continue
+                rows.append(f"{ctg['chr_id']}(+):{cmin[i]}-{cmax[i]}\t{gc}\t{int(mine['signal'][i])}\n")
+            else:
+                rng = f"{s}-{e}" if e != s else f"{s}"
+                rows.append(f"{ctg['chr_id']}:{rng}\t{gc}\t{int(mine['signal'][i])}\n")
+        out.append("".join(rows))
+    return out
+
+
+def test_device_rows_golden_and_against_the_host_merge(eng, s288c):
+    """gams_wave_rows_*: the reference's I.peaks.tsv byte for byte from device-made text; the same text as the host's
+    merge_ints + formatting over the peak records for steps 1 .. size, ragged ctgs with and without peaks, names of
+    different lengths, coverages that link every overlap; coverages that do not are refused (the host merges then)."""
+    ctgs = helpers.gen_ctgs("I", s288c["I"], piece=500000)
+    ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])
+    plan = engine.WavePlan(eng, ss, 100, 10, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS)
+    plan.rows_setup([c["chr_id"] for c in ctgs], [c["chr_start"] for c in ctgs], 0.2)
+    plan.run()
+    plan.rows_begin()
+    text, off = plan.rows_end()
+    assert HEADER + text.decode() == "\n".join(helpers.read_lines("I.peaks.tsv")) + "\n"
+    assert off.tolist() == [0, len(text)]
+    plan.close()
+    ss.close()
+    quiet = dict(id="ctg:quiet:1", chr_id="quiet", chr_start=5, chr_end=5 + 4000 - 1, seq=b"ACGT" * 1000)    # no peaks at all
+    ragged = (all_ctgs(s288c, piece=30000)[:5] + [quiet] + all_ctgs(s288c, piece=30000)[5:]
+              + [dict(id="ctg:a-long_name.7:1", chr_id="a-long_name.7", chr_start=1_999_000_001, chr_end=1_999_000_001 + 25000 - 1,
+                      seq=bytes(s288c["Mito"][:25000])), quiet])
+    ss = engine.SeqSet(eng, [c["seq"] for c in ragged])
+    for size, step, lag, thr, cov in [(100, 10, 100, 3.0, 0.2), (100, 1, 100, 3.0, 0.2), (100, 10, 100, 3.0, 1.0),
+                                      (100, 100, 20, 2.0, 0.2), (100, 150, 20, 2.0, 0.2), (50, 7, 33, 2.0, 0.5),
+                                      (1, 1, 50, 2.0, 0.2), (100, 10, 100, -1.0, 0.2), (100, 3, 40, 1.0, 1.0)]:
+        plan = engine.WavePlan(eng, ss, size, step, lag, thr, 1.0, flags=_lib.WAVE_PEAKS)
+        plan.rows_setup([c["chr_id"] for c in ragged], [c["chr_start"] for c in ragged], cov)
+        for rep in range(2):                      # the second pass copies speculatively, sized by the first
+            plan.run()
+            plan.rows_begin()
+            text, off = plan.rows_end()
+        exp = _host_rows(ragged, plan.peaks(), size, step, cov)
+        got = [text[int(off[c]):int(off[c + 1])].decode() for c in range(len(ragged))]
+        assert got == exp, (size, step, lag, thr, cov)
+        assert int(off[-1]) == len(text)
+        plan.close()
+    plan = engine.WavePlan(eng, ss, 100, 10, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS)
+    with pytest.raises(_lib.GamsError) as ei:
+        plan.rows_setup([c["chr_id"] for c in ragged], [c["chr_start"] for c in ragged], 1.5)
+    assert ei.value.code == _lib.EUNSUPPORTED
+    with pytest.raises(_lib.GamsError) as ei:
+        plan.rows_begin()
+    assert ei.value.code == _lib.ESTATE
+    plan.close()
+    ss.close()
+
+
+def test_device_rows_of_several_plans_in_flight(eng, s288c):
+    """rows_begin of three plans on three lanes before the first rows_end: every plan gets its own text."""
+    batches = [all_ctgs(s288c, piece=40000)[k::3] for k in range(3)]
+    sets = [engine.SeqSet(eng, [c["seq"] for c in b]) for b in batches]
+    plans = [engine.WavePlan(eng, s, 100, 10, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS) for s in sets]
+    for j, (p, b) in enumerate(zip(plans, batches)):
+        p.set_lane(j)
+        p.set_pipelined(True)
+        p.rows_setup([c["chr_id"] for c in b], [c["chr_start"] for c in b], 0.2)
+    for rep in range(3):
+        for p in plans:
+            p.run()
+            p.rows_begin()
+        for p, b in zip(plans, batches):
+            text, off = p.rows_end()
+            assert text.decode() == host.wave(eng, b)
+    for p in plans:
+        p.close()
+    for s in sets:
+        s.close()
