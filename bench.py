@@ -465,7 +465,7 @@ def main():
     # run + peaks, pipelined: what a host that consumes the peaks pays per batch (wave.rs:157-214 reads them).
     # Batch j runs on lane j; while its kernel is in flight the oldest batch's peaks are packed on the device
     # (wave_offsets_kernel + wave_gather_kernel on the readback stream) and fetched into page-locked memory.
-    pass_with_peaks_ms = None
+    pass_with_peaks_ms, pass_with_rows_ms, rows_text_bytes, resident_to_tsv_ms = None, None, None, None
     if world == 1 and nb > 1:
         set_flight(True)
         for p in plans:
@@ -481,6 +481,38 @@ def main():
             plans[(i + 1) % nb].peaks_count()          # the batch queued nb - 1 steps ago
         eng.sync()
         pass_with_peaks_ms = (time.perf_counter() - t0) / k_steps * 1e3
+        # ... and with the rows: merged and formatted on the device (gams_wave_rows_*), the TSV text of the batch
+        # lands in page-locked memory: what wave.rs:157-214 produces, with no host merge / formatting left
+        pass_with_rows_ms, rows_text_bytes = None, None
+        try:
+            for p, b in zip(plans, batches):
+                p.rows_setup([c["chr_id"] for c in b], [c["chr_start"] for c in b], 0.2)
+            for i in range(2 * nb):
+                plans[i % nb].run()
+                plans[i % nb].rows_begin()
+                if i >= nb - 1:
+                    plans[(i + 1) % nb].rows_end(copy=False)
+            for i in range(nb - 1):
+                plans[(2 * nb + i + 1) % nb].rows_end(copy=False)
+            eng.sync()
+            t0 = time.perf_counter()
+            for i in range(k_steps):
+                if i >= nb:
+                    plans[i % nb].rows_end(copy=False)      # the rows queued nb steps ago, before the slot is reused
+                plans[i % nb].run()
+                plans[i % nb].rows_begin()
+            rows_text_bytes = [plans[(k_steps + j) % nb].rows_end(copy=False) for j in range(nb)]
+            eng.sync()
+            pass_with_rows_ms = (time.perf_counter() - t0) / k_steps * 1e3
+            # one batch alone, nothing in flight: resident sequence -> the batch's TSV text in host memory
+            t0 = time.perf_counter()
+            for i in range(30):
+                plans[i % nb].run()
+                plans[i % nb].rows_begin()
+                plans[i % nb].rows_end(copy=False)
+            resident_to_tsv_ms = (time.perf_counter() - t0) / 30 * 1e3
+        except _lib.GamsError as e:
+            pass_with_rows_ms = f"unavailable: {e}"
         for p in plans:
             p.set_pipelined(False)
         set_flight(False)
@@ -500,6 +532,8 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "pass_with_peaks_ms": pass_with_peaks_ms,
+            "pass_with_rows_ms": pass_with_rows_ms,
+            "resident_to_tsv_ms": resident_to_tsv_ms,
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
@@ -514,6 +548,7 @@ def main():
                 "windows_per_step": win_per_batch,
                 "resident_bytes_per_gpu": int(sum(sum(len(c["seq"]) for c in b) for b in batches)),
                 "peaks_per_step": [int(p.size) for p in peaks],
+                "rows_text_bytes_per_step": rows_text_bytes,
                 "exact_path_windows_per_rotation": int(n_exact),
                 "passes_in_flight": (min(nb, 4) if nb > 1 else (args.depth or 2)) if in_flight else 1,
                 "tapered_launches": "off in the timed region (passes in flight), on in the roofline leg (one pass at a time)"

@@ -52,12 +52,12 @@
 // gams_wave_rows_*: the plan's TSV rows made on the device (wave_rows.hpp)
 struct WaveRows {
     uint32_t dmax = 0, max_name = 0;
-    uint8_t *arena = nullptr;                 // RowCtg[n_ctg] | names | gc text table | ctg_off[n_ctg + 1] | out_sizes[4]
+    uint8_t *arena = nullptr;                 // RowCtg[n_ctg] | names | gc text table | words[4 + n_ctg + 1]
     size_t arena_bytes = 0;
     RowCtg *d_ctgs = nullptr;
     char *d_names = nullptr;
     uint8_t *d_gctab = nullptr;
-    unsigned long long *d_ctg_off = nullptr, *d_sizes = nullptr;
+    unsigned long long *d_words = nullptr;     // [0] records, [1] text bytes, [2] peaks, [3] fullest tile, [4 ..] ctg_off[n_ctg + 1]
     uint8_t *tmp = nullptr;                   // per-record and per-block tables, room for `cap` records
     size_t tmp_bytes = 0;
     uint64_t cap = 0;
@@ -67,6 +67,17 @@ struct WaveRows {
     size_t h_text_bytes = 0;
     unsigned long long *h_words = nullptr;    // page-locked: [0] records, [1] text bytes, [2] peaks (offsets kernel), [3] fullest tile, [4..] ctg_off
     size_t h_words_bytes = 0;
+    uint64_t copy_bytes = 0;                  // size of the speculative text copy (held by the captured graphs)
+    bool use_graph = true;
+    struct RowGraphKey {
+        const void *dense, *tmp, *text, *h_text, *peaks, *tile_cnt, *tile_off;
+        uint64_t dense_cap, cap, copy_bytes;
+        uint32_t tile_cap, nt;
+    };
+    struct RowGraph {
+        hipGraphExec_t exec = nullptr;
+        RowGraphKey key{};
+    } graph[gams_gpu::kMaxWays];
     uint64_t copied = 0;                      // text bytes the last begin() already sent to the host
     uint64_t last_bytes = 0;                  // text bytes of the previous pass (sizes the speculative copy)
     hipEvent_t done = nullptr;
@@ -682,6 +693,8 @@ void gams_wave_plan_destroy(gams_gpu_t *h, gams_wave_plan_t *p) {
         gams_pool_free(h, true, r->h_text, r->h_text_bytes);
         gams_pool_free(h, true, r->h_words, r->h_words_bytes);
         if (r->done) (void)hipEventDestroy(r->done);
+        for (auto &g : r->graph)
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
         delete r;
         p->rows = nullptr;
     }
@@ -1378,18 +1391,117 @@ RowTables rows_carve(uint8_t *base, uint64_t cap) {
     return t;
 }
 
-// queue everything of one rows pass on the readback stream, behind the run the readers look at
-int rows_queue(gams_gpu_t *h, gams_wave_plan_t *p) {
+// The kernels and copies of one rows pass over way `wi`, in order: launched on `st` as they are (graph == nullptr), or
+// added to `graph` as a chain of nodes.  (Built node by node rather than by stream capture: a capture is invalidated
+// by what OTHER host threads do meanwhile, and the host layer runs one thread per handle.)
+int rows_emit(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t wi, hipStream_t st, uint64_t copy_bytes, hipGraph_t graph) {
     WaveRows *r = p->rows;
     const size_t nt = p->tiles.size();
-    unsigned long long *const d_totals = p->d_tile_off + nt;
-    gams_wave_plan::Way &w = wave_read_way(p);
+    unsigned long long *d_totals = p->d_tile_off + nt;
+    gams_wave_plan::Way &w = p->way[wi];
+    const RowTables t = rows_carve(r->tmp, r->cap);
+    const uint32_t n_ctg = p->set->n_ctg;
+    RowArgs a{};
+    a.rec = p->d_dense;
+    a.n_rec = d_totals;
+    a.cap = std::min<uint64_t>(r->cap, p->dense_cap);
+    a.tile_cap = p->tile_cap;
+    a.ctgs = r->d_ctgs;
+    a.n_ctg = n_ctg;
+    a.names = r->d_names;
+    a.gctab = r->d_gctab;
+    a.size = (uint32_t)p->prm.size;
+    a.step = (uint32_t)p->prm.step;
+    a.dmax = r->dmax;
+    a.flags = t.flags;
+    a.headpos = t.headpos;
+    a.blk_head = t.blk_head;
+    a.tailwin = t.tailwin;
+    a.len = t.len;
+    a.blk_len = t.blk_len;
+    a.blk_off = t.blk_off;
+    a.nb_cap = t.nb_cap;
+    a.text = r->d_text;
+    a.text_cap = r->d_text_bytes;
+    a.words = r->d_words;
+    hipGraphNode_t last = nullptr;
+    hipError_t err = hipSuccess;
+    auto kernel = [&](const void *fn, unsigned grid, unsigned block, void **args) {
+        if (err != hipSuccess) return;
+        if (!graph) {
+            err = hipLaunchKernel(fn, dim3(grid), dim3(block), args, 0, st);
+            return;
+        }
+        hipKernelNodeParams kp{};
+        kp.func = const_cast<void *>(fn);
+        kp.gridDim = dim3(grid);
+        kp.blockDim = dim3(block);
+        kp.sharedMemBytes = 0;
+        kp.kernelParams = args;
+        kp.extra = nullptr;
+        hipGraphNode_t node = nullptr;
+        err = hipGraphAddKernelNode(&node, graph, last ? &last : nullptr, last ? 1 : 0, &kp);
+        last = node;
+    };
+    auto copy = [&](void *dst, const void *src, size_t bytes) {
+        if (err != hipSuccess || bytes == 0) return;
+        if (!graph) {
+            err = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+            return;
+        }
+        hipGraphNode_t node = nullptr;
+        err = hipGraphAddMemcpyNode1D(&node, graph, last ? &last : nullptr, last ? 1 : 0, dst, src, bytes, hipMemcpyDeviceToHost);
+        last = node;
+    };
+    // argument blocks (read when the launch / the node is made)
+    uint32_t *tile_cnt = w.d_tile_cnt;
+    uint32_t nt32 = (uint32_t)nt;
+    unsigned long long *tile_off = p->d_tile_off;
+    void *args_off1[] = {&tile_cnt, &nt32, &tile_off, &d_totals};
+    const gams_peak_t *slots = w.d_peaks;
+    uint32_t tile_cap = p->tile_cap;
+    const uint32_t *ctile_cnt = w.d_tile_cnt;
+    const unsigned long long *ctile_off = p->d_tile_off;
+    gams_peak_t *dense = p->d_dense;
+    unsigned long long dense_cap = p->dense_cap;
+    void *args_gather[] = {&slots, &tile_cap, &ctile_cnt, &ctile_off, &dense, &dense_cap};
+    void *args_rows[] = {&a};
+    const uint32_t *blk_len = t.blk_len;
+    uint32_t nb = t.nb_cap;
+    unsigned long long *blk_off = t.blk_off, *blk_tot = t.blk_off + nb;
+    void *args_off2[] = {&blk_len, &nb, &blk_off, &blk_tot};
+    kernel(reinterpret_cast<const void *>(wave_offsets_kernel), 1, 1024, args_off1);
+    kernel(reinterpret_cast<const void *>(wave_gather_kernel), (unsigned)nt, 64, args_gather);
+    kernel(reinterpret_cast<const void *>(rows_link_kernel), nb, 256, args_rows);
+    kernel(reinterpret_cast<const void *>(rows_heads_kernel), 1, 1024, args_rows);
+    kernel(reinterpret_cast<const void *>(rows_tail_kernel), (unsigned)((r->cap + 255) / 256), 256, args_rows);
+    kernel(reinterpret_cast<const void *>(rows_len_kernel), nb, 256, args_rows);
+    kernel(reinterpret_cast<const void *>(wave_offsets_kernel), 1, 1024, args_off2);
+    kernel(reinterpret_cast<const void *>(rows_write_kernel), nb, 256, args_rows);
+    // the words (sizes, totals, per-ctg offsets: one block) and -- sized by the previous pass -- the text itself go to the
+    // host behind the kernels
+    copy(r->h_words, r->d_words, ((size_t)n_ctg + 1 + 4) * 8);
+    copy(r->h_text, r->d_text, copy_bytes);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        return gams_fail(h, GAMS_EHIP, std::string("wave_rows: ") + hipGetErrorString(err));
+    }
+    return GAMS_OK;
+}
+
+// queue everything of one rows pass on the readback stream, behind the run the readers look at.  The dozen launches
+// and copies are one graph per way (a plan's buffers do not move between passes; the graph is rebuilt when one does): one
+// call instead of ten on the host thread that also queues the passes themselves.
+int rows_queue(gams_gpu_t *h, gams_wave_plan_t *p) {
+    WaveRows *r = p->rows;
+    const uint32_t wi = wave_read_way_index(p);
+    gams_wave_plan::Way &w = p->way[wi];
     hipStream_t st = h->readback;
     if (p->pipelined && w.done) {
         GAMS_HIP(h, hipStreamWaitEvent(st, w.done, 0));
     } else {
         if (!w.ran_ev) GAMS_HIP(h, hipEventCreateWithFlags(&w.ran_ev, hipEventDisableTiming));
-        GAMS_HIP(h, hipEventRecord(w.ran_ev, wave_stream(h, p, wave_read_way_index(p))));
+        GAMS_HIP(h, hipEventRecord(w.ran_ev, wave_stream(h, p, wi)));
         GAMS_HIP(h, hipStreamWaitEvent(st, w.ran_ev, 0));
     }
     if (!p->d_dense) {
@@ -1413,59 +1525,47 @@ int rows_queue(gams_gpu_t *h, gams_wave_plan_t *p) {
         r->d_text_bytes = 0;
         GAMS_HIP(h, gams_pool_alloc(h, false, want_text, reinterpret_cast<void **>(&r->d_text), &r->d_text_bytes));
     }
-    const RowTables t = rows_carve(r->tmp, r->cap);
-    hipLaunchKernelGGL(wave_offsets_kernel, dim3(1), dim3(1024), 0, st, w.d_tile_cnt, (uint32_t)nt, p->d_tile_off, d_totals);
-    hipLaunchKernelGGL(wave_gather_kernel, dim3((unsigned)nt), dim3(64), 0, st, w.d_peaks, p->tile_cap, w.d_tile_cnt,
-                       p->d_tile_off, p->d_dense, (unsigned long long)p->dense_cap);
-    GAMS_HIP(h, hipGetLastError());
-    const uint32_t n_ctg = p->set->n_ctg;
-    GAMS_HIP(h, hipMemsetAsync(r->d_ctg_off, 0xFF, ((size_t)n_ctg + 1) * 8, st));
-    RowArgs a{};
-    a.rec = p->d_dense;
-    a.n_rec = d_totals;
-    a.cap = std::min<uint64_t>(r->cap, p->dense_cap);
-    a.tile_cap = p->tile_cap;
-    a.ctgs = r->d_ctgs;
-    a.names = r->d_names;
-    a.gctab = r->d_gctab;
-    a.size = (uint32_t)p->prm.size;
-    a.step = (uint32_t)p->prm.step;
-    a.dmax = r->dmax;
-    a.flags = t.flags;
-    a.headpos = t.headpos;
-    a.blk_head = t.blk_head;
-    a.tailwin = t.tailwin;
-    a.len = t.len;
-    a.blk_len = t.blk_len;
-    a.blk_off = t.blk_off;
-    a.nb_cap = t.nb_cap;
-    a.text = r->d_text;
-    a.text_cap = r->d_text_bytes;
-    a.ctg_off = r->d_ctg_off;
-    a.out_sizes = r->d_sizes;
-    const unsigned nb = t.nb_cap;
-    hipLaunchKernelGGL(rows_link_kernel, dim3(nb), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(rows_heads_kernel, dim3(1), dim3(1024), 0, st, a);
-    hipLaunchKernelGGL(rows_tail_kernel, dim3((unsigned)((r->cap + 255) / 256)), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(rows_len_kernel, dim3(nb), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(wave_offsets_kernel, dim3(1), dim3(1024), 0, st, t.blk_len, nb, t.blk_off, t.blk_off + nb);
-    hipLaunchKernelGGL(rows_write_kernel, dim3(nb), dim3(256), 0, st, a);
-    GAMS_HIP(h, hipGetLastError());
-    // sizes, per-ctg offsets and -- sized by the previous pass -- the text itself go to the host behind the kernels
-    GAMS_HIP(h, hipMemcpyAsync(r->h_words, r->d_sizes, 2 * 8, hipMemcpyDeviceToHost, st));
-    GAMS_HIP(h, hipMemcpyAsync(r->h_words + 2, d_totals, 2 * 8, hipMemcpyDeviceToHost, st));
-    GAMS_HIP(h, hipMemcpyAsync(r->h_words + 4, r->d_ctg_off, ((size_t)n_ctg + 1) * 8, hipMemcpyDeviceToHost, st));
-    r->copied = 0;
-    if (r->last_bytes) {
-        const uint64_t guess = std::min<uint64_t>(r->d_text_bytes, r->last_bytes + r->last_bytes / 8 + 4096);
-        if (r->h_text_bytes < guess) {
-            gams_pool_free(h, true, r->h_text, r->h_text_bytes);
-            r->h_text = nullptr;
-            r->h_text_bytes = 0;
-            GAMS_HIP(h, gams_pool_alloc(h, true, guess, reinterpret_cast<void **>(&r->h_text), &r->h_text_bytes));
+    // the text's speculative copy: sized by the previous pass, kept while it still fits (the graph holds the size)
+    uint64_t copy_bytes = r->copy_bytes;
+    if (r->last_bytes && (copy_bytes < r->last_bytes || copy_bytes > 2 * r->last_bytes + (1u << 20)))
+        copy_bytes = std::min<uint64_t>(r->d_text_bytes, (r->last_bytes + r->last_bytes / 8 + 65536) & ~(uint64_t)65535);
+    if (copy_bytes > r->h_text_bytes) {
+        gams_pool_free(h, true, r->h_text, r->h_text_bytes);
+        r->h_text = nullptr;
+        r->h_text_bytes = 0;
+        GAMS_HIP(h, gams_pool_alloc(h, true, copy_bytes, reinterpret_cast<void **>(&r->h_text), &r->h_text_bytes));
+    }
+    r->copy_bytes = copy_bytes;
+    r->copied = copy_bytes;
+    const WaveRows::RowGraphKey key{p->d_dense, r->tmp, r->d_text, r->h_text, w.d_peaks, w.d_tile_cnt, p->d_tile_off, p->dense_cap,
+                          r->cap, copy_bytes, p->tile_cap, (uint32_t)p->tiles.size()};
+    WaveRows::RowGraph &g = r->graph[wi];
+    bool launched = false;
+    if (r->use_graph) {
+        if (!g.exec || std::memcmp(&g.key, &key, sizeof key) != 0) {
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            g.exec = nullptr;
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipGraphCreate(&graph, 0);
+            if (e == hipSuccess && rows_emit(h, p, wi, st, copy_bytes, graph) != GAMS_OK) e = hipErrorUnknown;
+            if (e == hipSuccess) e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+            if (graph) (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                g.exec = nullptr;
+                r->use_graph = false;       // this runtime will not take the graph: plain launches from here on
+            } else {
+                g.key = key;
+            }
         }
-        GAMS_HIP(h, hipMemcpyAsync(r->h_text, r->d_text, guess, hipMemcpyDeviceToHost, st));
-        r->copied = guess;
+        if (g.exec) {
+            GAMS_HIP(h, hipGraphLaunch(g.exec, st));
+            launched = true;
+        }
+    }
+    if (!launched) {
+        const int rc = rows_emit(h, p, wi, st, copy_bytes, nullptr);
+        if (rc != GAMS_OK) return rc;
     }
     if (!r->done) GAMS_HIP(h, hipEventCreateWithFlags(&r->done, hipEventDisableTiming));
     GAMS_HIP(h, hipEventRecord(r->done, st));
@@ -1505,6 +1605,10 @@ int gams_wave_rows_setup(gams_gpu_t *h, gams_wave_plan_t *p, const char *const *
         gams_pool_free(h, true, r->h_words, r->h_words_bytes);
         r->arena = nullptr;
         r->h_words = nullptr;
+        for (auto &g : r->graph) {
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            g.exec = nullptr;
+        }
     } else {
         p->rows = new WaveRows();
     }
@@ -1533,14 +1637,13 @@ int gams_wave_rows_setup(gams_gpu_t *h, gams_wave_plan_t *p, const char *const *
         std::memcpy(&gct[(size_t)k * kGcStride + 1], t.data(), t.size());
     }
     const size_t b_ctgs = wave_align256(rc.size() * sizeof(RowCtg)), b_names = wave_align256(std::max<size_t>(blob.size(), 1)),
-                 b_gc = wave_align256(gct.size()), b_off = wave_align256(((size_t)n_ctg + 1) * 8), b_sz = 256;
-    GAMS_HIP(h, gams_pool_alloc(h, false, b_ctgs + b_names + b_gc + b_off + b_sz, reinterpret_cast<void **>(&r->arena),
+                 b_gc = wave_align256(gct.size()), b_words = wave_align256(((size_t)n_ctg + 1 + 4) * 8);
+    GAMS_HIP(h, gams_pool_alloc(h, false, b_ctgs + b_names + b_gc + b_words, reinterpret_cast<void **>(&r->arena),
                                 &r->arena_bytes));
     r->d_ctgs = reinterpret_cast<RowCtg *>(r->arena);
     r->d_names = reinterpret_cast<char *>(r->arena + b_ctgs);
     r->d_gctab = r->arena + b_ctgs + b_names;
-    r->d_ctg_off = reinterpret_cast<unsigned long long *>(r->arena + b_ctgs + b_names + b_gc);
-    r->d_sizes = reinterpret_cast<unsigned long long *>(r->arena + b_ctgs + b_names + b_gc + b_off);
+    r->d_words = reinterpret_cast<unsigned long long *>(r->arena + b_ctgs + b_names + b_gc);
     GAMS_HIP(h, hipMemcpy(r->d_ctgs, rc.data(), rc.size() * sizeof(RowCtg), hipMemcpyHostToDevice));
     if (!blob.empty()) GAMS_HIP(h, hipMemcpy(r->d_names, blob.data(), blob.size(), hipMemcpyHostToDevice));
     GAMS_HIP(h, hipMemcpy(r->d_gctab, gct.data(), gct.size(), hipMemcpyHostToDevice));

@@ -56,8 +56,9 @@ struct RowArgs {
     uint32_t nb_cap;                         // blocks the tables have room for = cap / kRowsBlock rounded up
     char *text;
     uint64_t text_cap;
-    unsigned long long *ctg_off;             // per ctg (+1): where its rows begin; ~0 where a ctg has none (the host fills those)
-    unsigned long long *out_sizes;           // [0] = records, [1] = text bytes  (copied to the host)
+    uint32_t n_ctg;
+    unsigned long long *words;               // what the host reads, one block: [0] records, [1] text bytes, [2] peaks, [3] fullest
+                                             // tile, [4 + c] where ctg c's rows begin (~0: it has none; the host fills those)
 };
 
 // Records to work on.  The packed records are only complete when no tile overflowed its slot and the packed
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256) void rows_link_kernel(const RowArgs a) {
 // exclusive prefix maximum over the blocks' last heads, in place (one workgroup)
 __global__ __launch_bounds__(1024) void rows_heads_kernel(const RowArgs a) {
     __shared__ int2 wtot[16];
+    for (uint32_t c = threadIdx.x; c <= a.n_ctg; c += 1024u) a.words[4u + c] = ~0ull;   // (rows_write_kernel sets the ctgs that have rows)
     const uint64_t n = rows_n(a);
     const uint32_t nb = (uint32_t)((n + kRowsBlock - 1) / kRowsBlock);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -254,8 +256,10 @@ __global__ __launch_bounds__(256) void rows_write_kernel(const RowArgs a) {
     __shared__ uint32_t scr[4];
     const uint64_t n = rows_n(a);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        a.out_sizes[0] = a.n_rec[0];
-        a.out_sizes[1] = a.blk_off[a.nb_cap];                  // all bytes (blocks past the last record count 0)
+        a.words[0] = a.n_rec[0];
+        a.words[1] = a.blk_off[a.nb_cap];                      // all bytes (blocks past the last record count 0)
+        a.words[2] = a.n_rec[0];
+        a.words[3] = a.n_rec[1];
     }
     const uint64_t base = (uint64_t)blockIdx.x * kRowsBlock;
     if (base >= n) return;
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(256) void rows_write_kernel(const RowArgs a) {
         const uint64_t i = base + 8u * tid + u;
         if (i >= n) break;
         const gams_peak_t r = a.rec[i];
-        if (i == 0 || a.rec[i - 1].ctg != r.ctg) a.ctg_off[r.ctg] = off;   // the ctg's rows begin here (its first record is a head)
+        if (i == 0 || a.rec[i - 1].ctg != r.ctg) a.words[4u + r.ctg] = off;   // the ctg's rows begin here (its first record is a head)
         if (l[u] && off + l[u] <= a.text_cap) {
             const uint8_t f = a.flags[i];
             const RowCtg cg = a.ctgs[r.ctg];
