@@ -45,6 +45,7 @@ WORKLOADS = {
     "S288c": ("S288C_LENGTHS", 500000, 100, 10, 100, "weak"),
     "Atha": ("ATHA_LENGTHS", 500000, 100, 10, 100, "weak"),
     "synth384": ("SYNTH384_LENGTHS", 1000000, 100, 10, 100, "weak"),
+    "synth384-step1": ("SYNTH384_LENGTHS", 1000000, 100, 1, 100, "weak"),     # configs[3]'s kernel on a genome that is quick to make
     "GRCh38-step10": ("GRCH38_LENGTHS", 1000000, 100, 10, 100, "strong"),
     "GRCh38-step1": ("GRCH38_LENGTHS", 1000000, 100, 1, 100, "strong"),
 }
