@@ -27,7 +27,9 @@
 
 namespace {
 
-constexpr uint32_t kRowsBlock = 2048;        // peaks per workgroup: 256 threads x 8
+constexpr uint32_t kRowsPer = 2;             // records per thread (a pass over 184 k records is ~360 workgroups: enough to fill the chip)
+constexpr uint32_t kRowsBlock = 256 * kRowsPer;   // records per workgroup
+constexpr uint32_t kRowsStage = 16384;       // bytes of a block's text staged in LDS by rows_write_kernel
 constexpr uint32_t kGcStride = 24;           // bytes per entry of the gc_content text table: [len][chars]
 constexpr uint8_t kRowHead = 1, kRowMerged = 2, kRowTail = 4;
 
@@ -89,12 +91,12 @@ __global__ __launch_bounds__(256) void rows_link_kernel(const RowArgs a) {
     const uint64_t base = (uint64_t)blockIdx.x * kRowsBlock;
     if (base >= n) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    // thread t owns records base + 8t .. +7 (consecutive: the prefix maximum runs through them in order)
+    // thread t owns kRowsPer consecutive records (the prefix maximum runs through them in order)
     int2 run = make_int2(-1, -1);
-    int2 mine[8];
+    int2 mine[kRowsPer];
 #pragma unroll
-    for (uint32_t u = 0; u < 8u; ++u) {
-        const uint64_t i = base + 8u * tid + u;
+    for (uint32_t u = 0; u < kRowsPer; ++u) {
+        const uint64_t i = base + kRowsPer * tid + u;
         mine[u] = make_int2(-1, -1);
         if (i >= n) continue;
         const gams_peak_t r = a.rec[i];
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void rows_link_kernel(const RowArgs a) {
             else
                 run.y = (int)(i - base);
         }
-        mine[u] = run;                                         // inclusive, inside this thread's eight
+        mine[u] = run;                                         // inclusive, inside this thread's own
     }
     // prefix maximum across the threads of the block (positions relative to the block, -1 = none)
     int2 inc = run;
@@ -147,8 +149,8 @@ __global__ __launch_bounds__(256) void rows_link_kernel(const RowArgs a) {
     excl.y = max(before.y, __shfl_up(inc.y, 1, 64));
     if (lane == 0u) excl = before;
 #pragma unroll
-    for (uint32_t u = 0; u < 8u; ++u) {
-        const uint64_t i = base + 8u * tid + u;
+    for (uint32_t u = 0; u < kRowsPer; ++u) {
+        const uint64_t i = base + kRowsPer * tid + u;
         if (i >= n) continue;
         const int hx = max(mine[u].x, excl.x), hy = max(mine[u].y, excl.y);
         // block-relative -> absolute (fits 32 bits: the rows path is limited to 2^31 records), -1 stays -1
@@ -239,8 +241,8 @@ __global__ __launch_bounds__(256) void rows_len_kernel(const RowArgs a) {
     const uint32_t tid = threadIdx.x;
     uint32_t sum = 0;
 #pragma unroll
-    for (uint32_t u = 0; u < 8u; ++u) {
-        const uint64_t i = base + 8u * tid + u;
+    for (uint32_t u = 0; u < kRowsPer; ++u) {
+        const uint64_t i = base + kRowsPer * tid + u;
         if (i >= n) continue;
         const uint32_t l = row_len(a, i, a.rec[i], a.flags[i]);
         a.len[i] = l;
@@ -252,8 +254,42 @@ __global__ __launch_bounds__(256) void rows_len_kernel(const RowArgs a) {
     if (tid == 0u) a.blk_len[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
+// one row's bytes at p (global or LDS)
+__device__ __forceinline__ void row_put(const RowArgs &a, char *p, uint64_t i, const gams_peak_t r) {
+    const uint8_t f = a.flags[i];
+    const RowCtg cg = a.ctgs[r.ctg];
+    const uint32_t s = (uint32_t)cg.chr_start + r.window * a.step;
+    const uint32_t lastw = (f & kRowMerged) ? a.tailwin[i] : r.window;
+    const uint32_t e = (uint32_t)cg.chr_start + lastw * a.step + a.size - 1u;
+    for (uint32_t q = 0; q < cg.name_len; ++q) *p++ = a.names[cg.name_off + q];
+    if (f & kRowMerged) {
+        *p++ = '(';
+        *p++ = '+';
+        *p++ = ')';
+    }
+    *p++ = ':';
+    p += dec_digits(s);
+    put_dec_back(p, s);
+    if (e != s) {
+        *p++ = '-';
+        p += dec_digits(e);
+        put_dec_back(p, e);
+    }
+    *p++ = '\t';
+    const uint8_t *g = a.gctab + (size_t)r.gc_count * kGcStride;
+    for (uint32_t q = 0; q < g[0]; ++q) *p++ = (char)g[1u + q];
+    *p++ = '\t';
+    if (r.signal < 0) *p++ = '-';
+    *p++ = '1';
+    *p++ = '\n';
+}
+
+// The rows of a block are one contiguous stretch of the text: they are put together in LDS (where a row's ~28
+// single-byte stores cost nothing) and leave as 16-B stores on 16-B boundaries of the text, the ragged ends byte by
+// byte.  A block whose text does not fit the stage (long names) writes its rows straight to the text.
 __global__ __launch_bounds__(256) void rows_write_kernel(const RowArgs a) {
     __shared__ uint32_t scr[4];
+    __shared__ __align__(16) char stage[kRowsStage + 16];
     const uint64_t n = rows_n(a);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         a.words[0] = a.n_rec[0];
@@ -264,52 +300,45 @@ __global__ __launch_bounds__(256) void rows_write_kernel(const RowArgs a) {
     const uint64_t base = (uint64_t)blockIdx.x * kRowsBlock;
     if (base >= n) return;
     const uint32_t tid = threadIdx.x;
-    uint32_t l[8], mine = 0;
+    uint32_t l[kRowsPer], mine = 0;
 #pragma unroll
-    for (uint32_t u = 0; u < 8u; ++u) {
-        const uint64_t i = base + 8u * tid + u;
+    for (uint32_t u = 0; u < kRowsPer; ++u) {
+        const uint64_t i = base + kRowsPer * tid + u;
         l[u] = i < n ? a.len[i] : 0u;
         mine += l[u];
     }
     uint32_t tot;
-    uint64_t off = a.blk_off[blockIdx.x] + block_excl_scan_256<uint32_t>(mine, scr, tot);
+    const uint32_t rel = block_excl_scan_256<uint32_t>(mine, scr, tot);
+    const uint64_t blk0 = a.blk_off[blockIdx.x];               // the block's first byte in the text
+    const uint32_t mis = (uint32_t)(blk0 & 15u);               // the stage starts at the same offset inside a 16-B unit
+    const bool staged = tot <= kRowsStage && blk0 + tot <= a.text_cap;
+    uint32_t at = rel;
 #pragma unroll
-    for (uint32_t u = 0; u < 8u; ++u) {
-        const uint64_t i = base + 8u * tid + u;
+    for (uint32_t u = 0; u < kRowsPer; ++u) {
+        const uint64_t i = base + kRowsPer * tid + u;
         if (i >= n) break;
         const gams_peak_t r = a.rec[i];
-        if (i == 0 || a.rec[i - 1].ctg != r.ctg) a.words[4u + r.ctg] = off;   // the ctg's rows begin here (its first record is a head)
-        if (l[u] && off + l[u] <= a.text_cap) {
-            const uint8_t f = a.flags[i];
-            const RowCtg cg = a.ctgs[r.ctg];
-            const uint32_t s = (uint32_t)cg.chr_start + r.window * a.step;
-            const uint32_t lastw = (f & kRowMerged) ? a.tailwin[i] : r.window;
-            const uint32_t e = (uint32_t)cg.chr_start + lastw * a.step + a.size - 1u;
-            char *p = a.text + off;
-            for (uint32_t q = 0; q < cg.name_len; ++q) *p++ = a.names[cg.name_off + q];
-            if (f & kRowMerged) {
-                *p++ = '(';
-                *p++ = '+';
-                *p++ = ')';
-            }
-            *p++ = ':';
-            p += dec_digits(s);
-            put_dec_back(p, s);
-            if (e != s) {
-                *p++ = '-';
-                p += dec_digits(e);
-                put_dec_back(p, e);
-            }
-            *p++ = '\t';
-            const uint8_t *g = a.gctab + (size_t)r.gc_count * kGcStride;
-            for (uint32_t q = 0; q < g[0]; ++q) *p++ = (char)g[1u + q];
-            *p++ = '\t';
-            if (r.signal < 0) *p++ = '-';
-            *p++ = '1';
-            *p++ = '\n';
+        if (i == 0 || a.rec[i - 1].ctg != r.ctg) a.words[4u + r.ctg] = blk0 + at;   // the ctg's rows begin here (its first record is a head)
+        if (l[u]) {
+            if (staged)
+                row_put(a, stage + mis + at, i, r);
+            else if (blk0 + at + l[u] <= a.text_cap)
+                row_put(a, a.text + blk0 + at, i, r);
         }
-        off += l[u];
+        at += l[u];
     }
+    if (!staged) return;
+    __syncthreads();
+    // stage[mis, mis + tot) -> text[blk0, blk0 + tot): whole 16-B units in the middle
+    const uint32_t head = min(tot, (16u - mis) & 15u);          // bytes in front of the first 16-B boundary
+    char *const dst = a.text + blk0;
+    if (tid < head) dst[tid] = stage[mis + tid];
+    const uint32_t units = (tot - head) >> 4;
+    const uint4 *const su = reinterpret_cast<const uint4 *>(stage + mis + head);   // 16-B aligned: mis + head is 0 mod 16
+    uint4 *const du = reinterpret_cast<uint4 *>(dst + head);
+    for (uint32_t q = tid; q < units; q += 256u) du[q] = su[q];
+    const uint32_t done = head + (units << 4);
+    if (tid < tot - done) dst[done + tid] = stage[mis + done + tid];
 }
 
 }  // namespace

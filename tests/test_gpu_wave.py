@@ -730,7 +730,7 @@ def test_thresholding_sample_through_the_device(eng):
 def test_influence_fuzz_against_the_oracle(eng, s288c, seed):
     """Random (size, step, lag, threshold, influence) with influence != 1 on ragged batches: thresholds low enough
     that most windows signal (zones that run into each other, zones beyond the speculative cap, which the
-    resolver walks itself), lags at the edge of the repair path (lag 638 is the last one; 639 takes the
+    resolver walks itself), lags at the edge of the repair path (lag 598 is the last one; 599 takes the
     one-wavefront-per-ctg recurrence), sizes beyond 255 (generic tile kernel), steps beyond a tile (untiled kernels)."""
     rng = np.random.default_rng(1000 + seed)
     pool = [bytes(s288c["I"][:90_000]), synth(33_333, 40 + seed).tobytes(), bytes(s288c["Mito"][:20_000]),
@@ -743,7 +743,7 @@ def test_influence_fuzz_against_the_oracle(eng, s288c, seed):
         thr = float(rng.choice([0.3, 1.0, 2.0, 3.0, 3.0, 5.0]))
         infl = float(rng.choice([0.0, 0.0, 0.25, 0.5, 0.9, 0.999, 1.5, -0.5]))
         cases.append((size, step, lag, thr, infl))
-    cases += [(100, 10, 638, 2.0, 0.5), (100, 10, 639, 2.0, 0.5)] if seed == 0 else []
+    cases += [(100, 10, 598, 2.0, 0.5), (100, 10, 599, 2.0, 0.5)] if seed == 0 else []
     cases += [(100, 10, 100, 0.05, 0.0), (100, 1, 50, 1.0, 0.0)] if seed == 1 else []
     for size, step, lag, thr, infl in cases:
         seqs = [sq for sq in pool if (len(sq) - size) // step + 1 >= lag]
