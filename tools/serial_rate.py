@@ -34,9 +34,10 @@ def rate(ss, n_ctg, infl, thr=3.0, lag=100, step=10, cap=0):
 
 for infl in (1.0, 0.5, 0.0):
     rate(ss, len(ctgs), infl)
-for cap in (1, 2, 8, 16, 64):
-    for infl in (0.5, 0.0):
-        rate(ss, len(ctgs), infl, cap=cap)
+if len(sys.argv) > 1 and sys.argv[1] == "caps":
+    for cap in (1, 2, 4, 16, 64):
+        for infl in (0.5, 0.0):
+            rate(ss, len(ctgs), infl, cap=cap)
 for thr in (2.0, 1.0):
     rate(ss, len(ctgs), 0.5, thr)
 rate(ss, len(ctgs), 0.5, 3.0, 30)
