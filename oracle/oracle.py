@@ -14,7 +14,7 @@ _SO = os.path.join(_HERE, "libgams_oracle.so")
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "gams_oracle.c")
+    src = max((os.path.join(_HERE, f) for f in ("gams_oracle.c", "gams_ref.c", "gams_ref.h")), key=os.path.getmtime)
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s", "libgams_oracle.so"])
     return _SO
@@ -257,3 +257,47 @@ def peak_rows(ctg_id, chr_id, chr_start, chr_end, seq, peaks):
     sg = (C.c_char_p * max(n, 1))(*[p[2].encode() for p in peaks])
     return _take_str(lib().ora_peak_rows(ctg_id.encode(), chr_id.encode(), chr_start, chr_end, a.ctypes.data,
                                          _ptr(ps, C.c_int32), _ptr(pe, C.c_int32), sg, n))
+
+
+# ---- CPU twins of the C ABI (gams_ref.h): the ABI's argument lists over the functions above -----------------
+_ref = None
+
+
+def ref():
+    """libgams_oracle.so with the gams_ref_* prototypes bound: argument for argument what gams_amd/_lib.py binds
+    for the matching gams_gpu_* entry, without the handle / device objects."""
+    global _ref
+    if _ref is not None:
+        return _ref
+    L = lib()
+    VP, U64P = C.c_void_p, C.POINTER(C.c_uint64)
+
+    class WaveParams(C.Structure):
+        _fields_ = [("size", C.c_int32), ("step", C.c_int32), ("lag", C.c_uint32), ("threshold", C.c_float),
+                    ("influence", C.c_float)]
+
+    L.WaveParams = WaveParams
+    L.gams_ref_wave.restype = C.c_int
+    L.gams_ref_wave.argtypes = [VP, C.c_uint32, C.POINTER(WaveParams), VP, VP, C.POINTER(C.c_uint32)]
+    L.gams_ref_wave_peaks.restype = C.c_int
+    L.gams_ref_wave_peaks.argtypes = [C.c_uint32, VP, VP, C.POINTER(WaveParams), VP, C.c_uint64, U64P]
+    L.gams_ref_wave_rows.restype = C.c_int
+    L.gams_ref_wave_rows.argtypes = [C.c_char_p, C.c_int32, VP, C.c_uint32, C.POINTER(WaveParams), C.c_float,
+                                     C.POINTER(C.c_void_p), U64P]
+    L.gams_ref_sw.restype = C.c_int
+    L.gams_ref_sw.argtypes = [VP, C.c_uint32, C.c_int32, VP, VP, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, VP,
+                              C.c_uint64, U64P]
+    L.gams_ref_range_gc.restype = C.c_int
+    L.gams_ref_range_gc.argtypes = [VP, C.c_uint32, C.c_int32, VP, VP, C.c_uint32, VP]
+    L.gams_ref_count.restype = C.c_int
+    L.gams_ref_count.argtypes = [C.c_uint32, VP, VP, VP, VP, VP, VP, C.c_uint64, VP]
+    L.gams_ref_locate.restype = C.c_int
+    L.gams_ref_locate.argtypes = [C.c_uint32, VP, VP, VP, VP, VP, VP, C.c_uint64, VP]
+    L.gams_ref_cover.restype = C.c_int
+    L.gams_ref_cover.argtypes = [C.c_uint32, VP, VP, VP, VP, VP, VP, VP, VP, C.c_uint64, VP]
+    L.gams_ref_valid_spans.restype = C.c_int
+    L.gams_ref_valid_spans.argtypes = [VP, C.c_uint64, C.c_int32, C.c_int32, VP, VP, C.c_uint64, U64P]
+    L.gams_ref_free.restype = None
+    L.gams_ref_free.argtypes = [VP]
+    _ref = L
+    return L
