@@ -65,7 +65,6 @@ PROTOTYPES = {
     "gams_wave_plan_set_taper": (C.c_int, [_VP, _VP, C.c_int]),
     "gams_wave_plan_set_taper_shape": (C.c_int, [_VP, _VP, C.c_int, C.c_int]),
     "gams_wave_plan_set_queue_threads": (C.c_int, [_VP, _VP, C.c_uint32]),
-    "gams_wave_plan_set_zone_cap": (C.c_int, [_VP, _VP, C.c_uint32]),
     "gams_wave_plan_kernel_name": (C.c_int, [_VP, _VP, C.c_char_p, C.c_size_t]),
     "gams_wave_plan_set_pipelined": (C.c_int, [_VP, _VP, C.c_int]),
     "gams_wave_run": (C.c_int, [_VP, _VP]),

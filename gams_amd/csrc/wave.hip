@@ -90,8 +90,11 @@ struct gams_wave_plan {
     gams_wave_params_t prm{};
     uint32_t flags = 0;
     bool serial = false;          // influence != 1
-    bool repair = false;          // ... by speculate-and-repair (wave_repair.hpp): the kernels run as for influence == 1 into
-                                  // the dense rows, zones behind the signals are then walked in parallel
+    bool repair = false;          // ... by guess-and-iterate (wave_repair.hpp): the kernels run as for influence == 1 into
+                                  // the dense rows, then filtered[] and the signals are iterated to their fixed point
+    JacTile *d_jtiles = nullptr;  // repair: tiles of 256 windows (pooled block)
+    size_t d_jtiles_bytes = 0;
+    uint32_t n_jtiles = 0;
     float *d_xtab = nullptr;      // repair: xtab[k] = k as f32 / size as f32, [size + 1] (inside arena_fixed)
     bool direct = false;          // halo beyond a tile: one lane per window, no tiling (wave_direct_*_kernel)
     bool wide = false, k16 = false;
@@ -120,8 +123,12 @@ struct gams_wave_plan {
         int8_t *d_dense_sig = nullptr;
         float *d_filtered = nullptr;
         size_t d_dense_cnt_bytes = 0, d_dense_sig_bytes = 0, d_filtered_bytes = 0;
-        uint8_t *d_zone = nullptr;              // repair: one pooled block, carved by wave_zone_carve
-        size_t d_zone_bytes = 0;
+        uint8_t *d_jac = nullptr;               // repair: filtered[] | dirty blocks | control words (one pooled block)
+        size_t d_jac_bytes = 0;
+        unsigned long long *h_ctl = nullptr;    // page-locked copy of the control words, made behind every batch of sweeps
+        size_t h_ctl_bytes = 0;
+        uint32_t jac_sweeps = 0;                // sweeps queued for the way's current pass
+        bool jac_settled = true;                // the host has seen a sweep without a flip (or ran the fallback)
         hipEvent_t done = nullptr;              // pipelined mode: recorded behind each run's kernels
         hipEvent_t ran_ev = nullptr;            // lets the readback stream queue behind the last run
         uint64_t seen_upload = 0;               // seqset upload generation this way's stream has waited for
@@ -133,8 +140,6 @@ struct gams_wave_plan {
     int taper_req = -1;                         // gams_wave_plan_set_taper: -1 auto, 0 off, 1 on
     bool taper = false;                         // the tile table ends in W = 8 and W = 4 tiles (wave_fast_taper_kernel)
     int taper4_pct = 25, taper8_pct = 50;       // size of the two tails, % of a round of workgroup slots (gams_wave_plan_set_taper_shape)
-    uint32_t zone_cap_mult = 8;                 // repair: windows of a speculative zone walk, in multiples of lag + 1 (gams_wave_plan_set_zone_cap;
-                                                // 30-Mb chromosome, influence 0.5 / 0.0: x4 4.1 / 6.8 ms, x8 2.8 / 3.5 ms, more: the same)
     uint32_t queue_threads = gams_gpu::kMaxWays;   // host threads gams_wave_run_n queues from (gams_wave_plan_set_queue_threads)
     uint32_t last_way = 0;                      // way of the most recent run
     uint32_t sel_age = 0;                       // readers look at the run `sel_age` before the most recent one
@@ -468,35 +473,24 @@ int wave_upload_geometry(gams_gpu_t *h, gams_wave_plan_t *p) {
     return GAMS_OK;
 }
 
-// The repair path's device tables of one way, carved from one pooled block.  Every S1 signal may start a
-// zone and every window may be an S1 signal, so the per-signal tables have one entry per window.
-struct ZoneBufs {
-    uint32_t *blk_cnt;               // S1 signals per block of kZoneBlock rows
-    unsigned long long *blk_off;     // their exclusive prefix (+ 2 totals: all signals, fullest block)
-    uint32_t *zlist;                 // rows of the S1 signals, ascending
-    uint2 *zinfo;                    // per S1 signal: zone end, next S1 signal behind it
-    uint32_t *vlist;                 // per ctg (at its first signal's index): the zones to commit
-    uint32_t *vcount, *pbase;        // per ctg
-    unsigned long long *vstart;      // exclusive prefix of vcount (+ 2 totals)
+// The repair path's device tables of one way, carved from one pooled block
+struct JacBufs {
+    float *f;                        // filtered[], one per row
+    uint32_t *fblk;                  // per block of kJacTile rows: 1 + the sweep in which filtered last changed there
+    unsigned long long *ctl;         // kJacWords control words
     size_t bytes;
 };
-ZoneBufs wave_zone_carve(uint8_t *base, uint64_t total_windows, uint32_t n_ctg) {
-    const size_t nb = (size_t)((total_windows + kZoneBlock - 1) / kZoneBlock);
+JacBufs wave_jac_carve(uint8_t *base, uint64_t total_windows) {
     size_t o = 0;
     auto take = [&](size_t b) {
         uint8_t *q = base ? base + o : nullptr;
         o += wave_align256(b);
         return q;
     };
-    ZoneBufs z{};
-    z.blk_cnt = reinterpret_cast<uint32_t *>(take(std::max<size_t>(nb, 1) * 4));
-    z.blk_off = reinterpret_cast<unsigned long long *>(take((nb + 2) * 8));
-    z.zlist = reinterpret_cast<uint32_t *>(take(std::max<uint64_t>(total_windows, 1) * 4));
-    z.zinfo = reinterpret_cast<uint2 *>(take(std::max<uint64_t>(total_windows, 1) * 8));
-    z.vlist = reinterpret_cast<uint32_t *>(take(std::max<uint64_t>(total_windows, 1) * 4));
-    z.vcount = reinterpret_cast<uint32_t *>(take(std::max<size_t>(n_ctg, 1) * 4));
-    z.pbase = reinterpret_cast<uint32_t *>(take(std::max<size_t>(n_ctg, 1) * 4));
-    z.vstart = reinterpret_cast<unsigned long long *>(take(((size_t)n_ctg + 2) * 8));
+    JacBufs z{};
+    z.f = reinterpret_cast<float *>(take(std::max<uint64_t>(total_windows, 1) * 4));
+    z.fblk = reinterpret_cast<uint32_t *>(take((size_t)(total_windows / kJacTile + 2) * 4));
+    z.ctl = reinterpret_cast<unsigned long long *>(take(kJacWords * 8));
     z.bytes = o;
     return z;
 }
@@ -524,12 +518,10 @@ int wave_alloc_ways(gams_gpu_t *h, gams_wave_plan_t *p) {
         if (p->serial && !p->repair && !w.d_filtered)
             GAMS_HIP(h, gams_pool_alloc(h, false, base * sizeof(float), reinterpret_cast<void **>(&w.d_filtered),
                                         &w.d_filtered_bytes));
-        if (p->repair && !w.d_zone) {
-            const hipError_t e = gams_pool_alloc(h, false, wave_zone_carve(nullptr, p->total_windows, p->set->n_ctg).bytes,
-                                                 reinterpret_cast<void **>(&w.d_zone), &w.d_zone_bytes);
-            if (e == hipErrorOutOfMemory)
-                return gams_fail(h, GAMS_ENOMEM, "wave: no memory for the influence != 1 tables (16 B per window)");
-            GAMS_HIP(h, e);
+        if (p->repair && !w.d_jac) {
+            GAMS_HIP(h, gams_pool_alloc(h, false, wave_jac_carve(nullptr, p->total_windows).bytes,
+                                        reinterpret_cast<void **>(&w.d_jac), &w.d_jac_bytes));
+            GAMS_HIP(h, gams_pool_alloc(h, true, kJacWords * 8, reinterpret_cast<void **>(&w.h_ctl), &w.h_ctl_bytes));
         }
     }
     return GAMS_OK;
@@ -620,10 +612,9 @@ int gams_wave_plan_create(gams_gpu_t *h, gams_seqset_t *s, const gams_wave_param
         base += (uint64_t)n;
     }
     p->total_windows = base;
-    // influence != 1: speculate-and-repair while a wavefront's 64 rings of lag + 2 floats fit the LDS and the
-    // dense rows can be indexed with 32 bits; the one-wavefront-per-ctg recurrence beyond that
-    p->repair = p->serial && params->lag >= 2 && ((size_t)params->lag + 2) * 256 <= 150 * 1024 &&
-                base < 0xFFFFFFFFull - 4 * kZoneBlock;
+    // influence != 1: guess-and-iterate while a tile's history (256 + lag + 1 floats) fits a comfortable share of the
+    // LDS; the one-wavefront-per-ctg recurrence beyond that
+    p->repair = p->serial && params->lag >= 2 && params->lag <= 16000;
     int rc = wave_build_geometry(h, p, 0);
     if (rc != GAMS_OK) {
         delete p;
@@ -657,6 +648,15 @@ int gams_wave_plan_create(gams_gpu_t *h, gams_seqset_t *s, const gams_wave_param
             std::vector<float> xt((size_t)params->size + 1);
             for (size_t k = 0; k < xt.size(); ++k) xt[k] = (float)k / (float)params->size;
             PLAN_HIP(hipMemcpy(p->d_xtab, xt.data(), xt.size() * sizeof(float), hipMemcpyHostToDevice));
+            std::vector<JacTile> jt;
+            for (uint32_t c = 0; c < s->n_ctg; ++c)
+                for (uint32_t w0 = 0; w0 < p->ctgs[c].n_win; w0 += kJacTile)
+                    jt.push_back(JacTile{c, w0, p->ctgs[c].n_win, 0u, p->ctgs[c].win_base});
+            p->n_jtiles = (uint32_t)jt.size();
+            PLAN_HIP(gams_pool_alloc(h, false, std::max<size_t>(jt.size(), 1) * sizeof(JacTile),
+                                     reinterpret_cast<void **>(&p->d_jtiles), &p->d_jtiles_bytes));
+            if (!jt.empty())
+                PLAN_HIP(hipMemcpy(p->d_jtiles, jt.data(), jt.size() * sizeof(JacTile), hipMemcpyHostToDevice));
         }
     }
     if (s->n_ctg)
@@ -700,6 +700,7 @@ void gams_wave_plan_destroy(gams_gpu_t *h, gams_wave_plan_t *p) {
     }
     gams_pool_free(h, false, p->arena_fixed, p->arena_fixed_bytes);
     gams_pool_free(h, false, p->arena_geom, p->arena_geom_bytes);
+    gams_pool_free(h, false, p->d_jtiles, p->d_jtiles_bytes);
     gams_pool_free(h, false, p->d_dense, p->d_dense_bytes);
     gams_pool_free(h, true, p->h_peaks, p->h_peaks_bytes);
     for (auto &w : p->way) {
@@ -708,7 +709,8 @@ void gams_wave_plan_destroy(gams_gpu_t *h, gams_wave_plan_t *p) {
         gams_pool_free(h, false, w.d_dense_cnt, w.d_dense_cnt_bytes);
         gams_pool_free(h, false, w.d_dense_sig, w.d_dense_sig_bytes);
         gams_pool_free(h, false, w.d_filtered, w.d_filtered_bytes);
-        gams_pool_free(h, false, w.d_zone, w.d_zone_bytes);
+        gams_pool_free(h, false, w.d_jac, w.d_jac_bytes);
+        gams_pool_free(h, true, w.h_ctl, w.h_ctl_bytes);
         if (w.done) (void)hipEventDestroy(w.done);
         if (w.ran_ev) (void)hipEventDestroy(w.ran_ev);
     }
@@ -748,6 +750,101 @@ int gams_wave_plan_set_guard(gams_gpu_t *h, gams_wave_plan_t *p, float safety, i
     p->guard_safety = safety;
     p->guard_exact = all_exact != 0;
     wave_set_band(p);
+    return GAMS_OK;
+}
+
+// ---- influence != 1: guess-and-iterate (wave_repair.hpp) ------------------------------------------------------
+constexpr uint32_t kJacFirstBatch = 6;      // sweeps queued with the pass (3-5 settle the usual case), then batches of 8
+
+static JacArgs wave_jac_args(gams_wave_plan_t *p, uint32_t k) {
+    gams_wave_plan::Way &w = p->way[k];
+    const JacBufs z = wave_jac_carve(w.d_jac, p->total_windows);
+    JacArgs a{};
+    a.tiles = p->d_jtiles;
+    a.n_tiles = p->n_jtiles;
+    a.cnt = w.d_dense_cnt;
+    a.sig = w.d_dense_sig;
+    a.xtab = p->d_xtab;
+    a.f = z.f;
+    a.fblk = z.fblk;
+    a.ctl = z.ctl;
+    a.lag = p->prm.lag;
+    a.sweep = 0;
+    a.thr = p->prm.threshold;
+    a.influence = p->prm.influence;
+    return a;
+}
+
+// the peaks of the dense rows into the tile slots (what the readers pack)
+static int wave_compact_dense(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k, hipStream_t st) {
+    gams_wave_plan::Way &w = p->way[k];
+    if (!(p->flags & GAMS_WAVE_PEAKS) || p->tiles.empty()) return GAMS_OK;
+    hipLaunchKernelGGL(wave_compact_kernel, dim3((unsigned)p->tiles.size()), dim3(256), 0, st, p->d_ctgs, p->d_tiles, p->tw,
+                       w.d_dense_cnt, w.d_dense_sig, w.d_peaks, p->tile_cap, w.d_tile_cnt);
+    GAMS_HIP(h, hipGetLastError());
+    return GAMS_OK;
+}
+
+// queue `n` more sweeps on way k's stream (first: with the initialisation in front), then the compaction of the dense
+// rows and the copy of the control words
+static int wave_jac_sweeps(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k, uint32_t n, bool first) {
+    gams_wave_plan::Way &w = p->way[k];
+    hipStream_t st = wave_stream(h, p, k);
+    JacArgs a = wave_jac_args(p, k);
+    const unsigned grid = std::max(p->n_jtiles, 1u);
+    const size_t lds = ((size_t)kJacTile + a.lag + 1) * sizeof(float);
+    GAMS_HIP(h, gams_lds_attr(h, reinterpret_cast<const void *>(jac_eval_kernel), lds));
+    if (first) hipLaunchKernelGGL(jac_init_kernel, dim3(grid), dim3(256), 0, st, a);
+    if (p->n_jtiles)
+        for (uint32_t i = 0; i < n && w.jac_sweeps < kJacMaxSweeps; ++i, ++w.jac_sweeps) {
+            a.sweep = w.jac_sweeps;
+            hipLaunchKernelGGL(jac_filter_kernel, dim3(grid), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(jac_eval_kernel, dim3(grid), dim3(256), lds, st, a);
+        }
+    GAMS_HIP(h, hipGetLastError());
+    int rc = wave_compact_dense(h, p, k, st);
+    if (rc != GAMS_OK) return rc;
+    GAMS_HIP(h, hipMemcpyAsync(w.h_ctl, a.ctl, kJacWords * 8, hipMemcpyDeviceToHost, st));
+    return GAMS_OK;
+}
+
+// Has way k's pass reached its fixed point?  Waits for what is queued, looks at the control words, queues more sweeps
+// while a sweep still flipped signals, and after kJacMaxSweeps (or at a run of thousands of signalled windows) lets the
+// one-wavefront-per-ctg recurrence compute the batch from the counts.  Every reader of a pass calls this first.
+static int wave_jac_settle(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
+    if (!p->repair) return GAMS_OK;
+    gams_wave_plan::Way &w = p->way[k];
+    if (w.jac_settled || p->n_jtiles == 0) return GAMS_OK;
+    hipStream_t st = wave_stream(h, p, k);
+    for (;;) {
+        GAMS_HIP(h, hipStreamSynchronize(st));
+        bool fixed = false;
+        for (uint32_t i = 0; i < w.jac_sweeps && !fixed; ++i) fixed = w.h_ctl[i] == 0ull;
+        const bool abandon = w.h_ctl[kJacAbandon] != 0ull;
+        if (fixed && !abandon) break;
+        if (abandon || w.jac_sweeps >= kJacMaxSweeps) {
+            const gams_wave_params_t &q = p->prm;
+            const uint32_t n = p->set->n_ctg;
+            if (q.lag + 1u <= kSerialRing) {
+                const size_t ring = (size_t)((q.lag + 1u + 63u) & ~63u) * sizeof(float);
+                GAMS_HIP(h, gams_lds_attr(h, reinterpret_cast<const void *>(wave_serial_wave_kernel), kSerialRing * sizeof(float)));
+                hipLaunchKernelGGL(wave_serial_wave_kernel, dim3(n), dim3(64), ring, st, p->d_ctgs, n, w.d_dense_cnt,
+                                   w.d_dense_sig, q.lag, q.threshold, q.influence, (float)q.size);
+            } else {
+                hipLaunchKernelGGL(wave_serial_kernel, dim3((n + 63) / 64), dim3(64), 0, st, p->d_ctgs, n, w.d_dense_cnt,
+                                   w.d_dense_sig, wave_jac_carve(w.d_jac, p->total_windows).f, q.lag, q.threshold, q.influence,
+                                   (float)q.size);
+            }
+            GAMS_HIP(h, hipGetLastError());
+            int rc = wave_compact_dense(h, p, k, st);
+            if (rc != GAMS_OK) return rc;
+            GAMS_HIP(h, hipStreamSynchronize(st));
+            break;
+        }
+        int rc = wave_jac_sweeps(h, p, k, 8, false);
+        if (rc != GAMS_OK) return rc;
+    }
+    w.jac_settled = true;
     return GAMS_OK;
 }
 
@@ -879,47 +976,13 @@ static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
         GAMS_HIP(h, hipGetLastError());
     }
     if (p->repair) {
-        // influence != 1, speculate-and-repair (wave_repair.hpp): the dense rows hold the counts and the S1
-        // signals; everything below is queued on the way's stream, no host wait
-        const uint64_t total = p->total_windows;
-        const ZoneBufs z = wave_zone_carve(w.d_zone, total, p->set->n_ctg);
-        const unsigned nb = (unsigned)((total + kZoneBlock - 1) / kZoneBlock);
-        ZoneArgs za{};
-        za.ctgs = p->d_ctgs;
-        za.n_ctg = p->set->n_ctg;
-        za.cnt = w.d_dense_cnt;
-        za.sig = w.d_dense_sig;
-        za.xtab = p->d_xtab;
-        za.zlist = z.zlist;
-        za.totals = z.blk_off + nb;
-        za.zinfo = z.zinfo;
-        za.lag = q.lag;
-        za.cap = (p->zone_cap_mult * (q.lag + 1u) + 1u) & ~1u;   // windows of a speculative zone walk (even: two per trip); longer zones are the resolver's
-        za.thr = q.threshold;
-        za.influence = q.influence;
-        za.n_xtab = (uint32_t)q.size + 1u;
-        const size_t ring_bytes = ((size_t)q.lag + 2) * 64 * sizeof(float) + (za.n_xtab <= kXtabLds ? za.n_xtab * sizeof(float) : 0);
-        const size_t resolve_bytes = (size_t)((q.lag + 2u + 63u) & ~63u) * sizeof(float) + (size_t)kResolveStage * sizeof(uint2);
-        const unsigned grid = (unsigned)std::max(h->cus, 1) * 8u;
-        GAMS_HIP(h, gams_lds_attr(h, reinterpret_cast<const void *>(zone_spec_kernel), ring_bytes));
-        GAMS_HIP(h, gams_lds_attr(h, reinterpret_cast<const void *>(zone_commit_kernel), ring_bytes));
-        GAMS_HIP(h, gams_lds_attr(h, reinterpret_cast<const void *>(zone_resolve_kernel), resolve_bytes));
-        hipLaunchKernelGGL(zone_count_kernel, dim3(nb), dim3(256), 0, st, w.d_dense_sig, total, z.blk_cnt);
-        hipLaunchKernelGGL(wave_offsets_kernel, dim3(1), dim3(1024), 0, st, z.blk_cnt, nb, z.blk_off, z.blk_off + nb);
-        hipLaunchKernelGGL(zone_scatter_kernel, dim3(nb), dim3(256), 0, st, w.d_dense_sig, total, z.blk_off, z.zlist);
-        hipLaunchKernelGGL(zone_spec_kernel, dim3(grid), dim3(64), ring_bytes, st, za);
-        hipLaunchKernelGGL(zone_resolve_kernel, dim3(std::min<unsigned>(za.n_ctg, grid)), dim3(64), resolve_bytes, st, za,
-                           z.vlist, z.vcount, z.pbase);
-        hipLaunchKernelGGL(wave_offsets_kernel, dim3(1), dim3(1024), 0, st, z.vcount, za.n_ctg, z.vstart,
-                           z.vstart + za.n_ctg);
-        hipLaunchKernelGGL(zone_commit_kernel, dim3(grid), dim3(64), ring_bytes, st, za, z.vlist, z.pbase, z.vstart,
-                           z.vstart + za.n_ctg);
-        GAMS_HIP(h, hipGetLastError());
-        if (p->flags & GAMS_WAVE_PEAKS) {
-            hipLaunchKernelGGL(wave_compact_kernel, dim3((unsigned)p->tiles.size()), dim3(256), 0, st, p->d_ctgs,
-                               p->d_tiles, p->tw, w.d_dense_cnt, w.d_dense_sig, w.d_peaks, p->tile_cap, w.d_tile_cnt);
-            GAMS_HIP(h, hipGetLastError());
-        }
+        // influence != 1, guess-and-iterate (wave_repair.hpp): the dense rows hold the counts and the S1 signals; a first
+        // batch of sweeps is queued behind them -- no host wait here; whoever reads the pass checks that it settled
+        // (wave_jac_settle) and queues more sweeps if it did not
+        w.jac_sweeps = 0;
+        w.jac_settled = false;
+        rc = wave_jac_sweeps(h, p, k, kJacFirstBatch, true);
+        if (rc != GAMS_OK) return rc;
     } else if (p->serial) {
         const uint32_t n = p->set->n_ctg;
         if (q.lag + 1u <= kSerialRing) {
@@ -1167,13 +1230,6 @@ int gams_wave_plan_set_taper_shape(gams_gpu_t *h, gams_wave_plan_t *p, int pct4,
     return rc;
 }
 
-int gams_wave_plan_set_zone_cap(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t mult) {
-    if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_plan_set_zone_cap: null argument");
-    if (mult < 1 || mult > 4096) return gams_fail(h, GAMS_EINVAL, "wave_plan_set_zone_cap: 1..4096");
-    p->zone_cap_mult = mult;
-    return GAMS_OK;
-}
-
 int gams_wave_plan_set_queue_threads(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t n) {
     if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_plan_set_queue_threads: null argument");
     if (n < 1 || n > (uint32_t)gams_gpu::kMaxWays)
@@ -1191,7 +1247,7 @@ int gams_wave_plan_kernel_name(gams_gpu_t *h, gams_wave_plan_t *p, char *buf, si
     const char *nt = p->set->bytes > kStreamBytes ? "true" : "false";
     std::string name;
     if (p->repair)
-        name = "zone_spec_kernel";     // of the pass's kernels (counts + S1 signals, zones, commit) the one that takes longest
+        name = "jac_eval_kernel";      // of the pass's kernels (counts + S1 signals, sweeps) the one that takes longest
     else if (p->serial)
         name = q.lag + 1u <= kSerialRing ? "wave_serial_wave_kernel" : "wave_serial_kernel";
     else if (p->direct)
@@ -1246,6 +1302,10 @@ int gams_wave_peaks(gams_gpu_t *h, gams_wave_plan_t *p, const gams_peak_t **peak
         return GAMS_OK;
     }
     for (int attempt = 0; attempt < 2; ++attempt) {
+        {
+            const int src = wave_jac_settle(h, p, wave_read_way_index(p));   // influence != 1: the pass has reached its fixed point
+            if (src != GAMS_OK) return src;
+        }
         // two words behind the offsets (re-read every attempt: a regrow replaces the arena)
         unsigned long long *const d_totals = p->d_tile_off + nt;
         // The readback stream queues behind the run (pipelined: behind this plan's run only, later
@@ -1496,6 +1556,10 @@ int rows_queue(gams_gpu_t *h, gams_wave_plan_t *p) {
     WaveRows *r = p->rows;
     const uint32_t wi = wave_read_way_index(p);
     gams_wave_plan::Way &w = p->way[wi];
+    {
+        const int src = wave_jac_settle(h, p, wi);      // influence != 1: the pass has reached its fixed point
+        if (src != GAMS_OK) return src;
+    }
     // The rows go on the stream the pass itself ran on: ordered behind it without an event, and the rows of plans
     // on different lanes run side by side (eight short dependent kernels and a 2-MB copy per batch: on one shared
     // stream they were 117 us per batch for three plans in flight, the passes themselves 22).
@@ -1746,7 +1810,8 @@ int gams_wave_dense(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t i, uint32_t *gc
     if (i >= p->ctgs.size()) return gams_fail(h, GAMS_EINVAL, "wave_dense: ctg index out of range");
     GAMS_HIP(h, hipSetDevice(h->device));
     {
-        int wrc = wave_wait_last_run(h, p);
+        int wrc = wave_jac_settle(h, p, wave_read_way_index(p));
+        if (wrc == GAMS_OK) wrc = wave_wait_last_run(h, p);
         if (wrc != GAMS_OK) return wrc;
     }
     const WaveCtgDev &c = p->ctgs[i];

@@ -182,10 +182,6 @@ class WavePlan:
             pct4, pct8 = divmod(int(pct4), 1000)
         self.eng.check(self.eng.lib.gams_wave_plan_set_taper_shape(self.eng.h, self.p, pct4, pct8))
 
-    def set_zone_cap(self, mult):
-        """influence != 1: speculative zone walks give up after mult * (lag + 1) windows (default 8)"""
-        self.eng.check(self.eng.lib.gams_wave_plan_set_zone_cap(self.eng.h, self.p, mult))
-
     def set_queue_threads(self, n):
         """host threads run_n queues a long batch of passes from (1..4)"""
         self.eng.check(self.eng.lib.gams_wave_plan_set_queue_threads(self.eng.h, self.p, n))

@@ -35,10 +35,6 @@ int gams_wave_plan_set_taper(gams_gpu_t *h, gams_wave_plan_t *plan, int mode);
  * holding the last pct4 % of a round are cut into the smallest tiles, the pct8 % before them into the
  * middle ones; at most 8 % / 17 % of the batch.  0..100, default 25 / 50 (profiles/r02_taper_sweep.txt). */
 int gams_wave_plan_set_taper_shape(gams_gpu_t *h, gams_wave_plan_t *plan, int pct4, int pct8);
-/* influence != 1 (speculate-and-repair, gams_amd/csrc/wave_repair.hpp): a speculative zone walk gives up after
- * mult * (lag + 1) windows (default 8); zones longer than that are walked to their end by the resolver, one
- * wavefront per ctg.  Results do not depend on it.  Applies to the next run. */
-int gams_wave_plan_set_zone_cap(gams_gpu_t *h, gams_wave_plan_t *plan, uint32_t mult);
 /* Host threads gams_wave_run_n queues a long batch of passes from (1..4, default one per way). */
 int gams_wave_plan_set_queue_threads(gams_gpu_t *h, gams_wave_plan_t *plan, uint32_t n);
 /* Name of the kernel that does the plan's work, spelled as rocprofv3 --kernel-trace prints the

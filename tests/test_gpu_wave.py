@@ -625,7 +625,7 @@ def test_plan_kernel_name_follows_the_plan(eng):
     assert names["step 1, 5120"] == "wave_fast_kernel<20, 100, 1, 100, false>"
     assert names["step 1, 7168"] == "wave_fast_kernel<28, 100, 1, 100, false>"
     assert names[(50, 7, 33, 1.0)] == "wave_fast_kernel<4, 0, 0, 0, false>"
-    assert names[(100, 10, 100, 0.5)] == "zone_spec_kernel"
+    assert names[(100, 10, 100, 0.5)] == "jac_eval_kernel"
     assert names[(100, 1000, 100, 1.0)].startswith("wave_direct_count_kernel")
 
 
@@ -711,7 +711,7 @@ def test_thresholding_sample_through_the_device(eng):
     for step_size, seqs in ((100, [seq]), (100, [seq, synth(30000, 3).tobytes(), seq])):
         ss = engine.SeqSet(eng, seqs)
         plan = engine.WavePlan(eng, ss, 100, step_size, 30, 5.0, 0.0, flags=_lib.WAVE_PEAKS | _lib.WAVE_DENSE)
-        assert plan.kernel_name() == "zone_spec_kernel"
+        assert plan.kernel_name() == "jac_eval_kernel"
         plan.run()
         pk = plan.peaks()
         for c, sq in enumerate(seqs):
@@ -729,9 +729,9 @@ def test_thresholding_sample_through_the_device(eng):
 @pytest.mark.parametrize("seed", range(6))
 def test_influence_fuzz_against_the_oracle(eng, s288c, seed):
     """Random (size, step, lag, threshold, influence) with influence != 1 on ragged batches: thresholds low enough
-    that most windows signal (zones that run into each other, zones beyond the speculative cap, which the
-    resolver walks itself), lags at the edge of the repair path (lag 598 is the last one; 599 takes the
-    one-wavefront-per-ctg recurrence), sizes beyond 255 (generic tile kernel), steps beyond a tile (untiled kernels)."""
+    that most windows signal (many sweeps; at influence 0 runs of thousands of signalled windows, which hand the batch
+    to the one-wavefront-per-ctg recurrence), lags far beyond a tile, sizes beyond 255 (generic tile kernel), steps beyond
+    a tile (untiled kernels)."""
     rng = np.random.default_rng(1000 + seed)
     pool = [bytes(s288c["I"][:90_000]), synth(33_333, 40 + seed).tobytes(), bytes(s288c["Mito"][:20_000]),
             synth(8_000, 50 + seed, gc=0.5, nrate=0.02).tobytes(), (b"ACGT" * 3000 + b"N" * 500 + b"GGCC" * 2000)]
@@ -743,8 +743,8 @@ def test_influence_fuzz_against_the_oracle(eng, s288c, seed):
         thr = float(rng.choice([0.3, 1.0, 2.0, 3.0, 3.0, 5.0]))
         infl = float(rng.choice([0.0, 0.0, 0.25, 0.5, 0.9, 0.999, 1.5, -0.5]))
         cases.append((size, step, lag, thr, infl))
-    cases += [(100, 10, 598, 2.0, 0.5), (100, 10, 599, 2.0, 0.5)] if seed == 0 else []
-    cases += [(100, 10, 100, 0.05, 0.0), (100, 1, 50, 1.0, 0.0)] if seed == 1 else []
+    cases += [(100, 10, 598, 2.0, 0.5), (100, 10, 1999, 2.0, 0.5)] if seed == 0 else []
+    cases += [(100, 10, 100, 0.05, 0.0), (100, 1, 50, 1.0, 0.0), (100, 10, 100, 2.0, 0.0), (100, 10, 100, 1.0, 0.999)] if seed == 1 else []
     for size, step, lag, thr, infl in cases:
         seqs = [sq for sq in pool if (len(sq) - size) // step + 1 >= lag]
         if not seqs:
