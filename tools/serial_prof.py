@@ -14,4 +14,4 @@ plan = engine.WavePlan(eng, ss, 100, 10, 100, thr, float(sys.argv[1]) if len(sys
 for _ in range(10):
     plan.run()
 eng.sync()
-print(plan.peaks().size)
+print(plan.peaks().size, plan.kernel_name())
