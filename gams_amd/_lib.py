@@ -84,6 +84,8 @@ PROTOTYPES = {
                               C.c_int32, _VP, C.c_uint64, C.POINTER(C.c_uint64)]),
     "gams_gpu_sw_batch": (C.c_int, [_VP, _VP, C.c_uint32, _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32, C.c_int32,
                                     _VP, C.c_uint64, _VP, _VP]),
+    "gams_gpu_sw_text": (C.c_int, [_VP, _VP, C.c_uint32, _VP, C.POINTER(C.c_char_p), _VP, _VP, _VP, _VP, C.POINTER(C.c_char_p),
+                                   C.c_int32, C.c_int32, C.c_int32, _PP, C.POINTER(C.c_uint64), _PP, C.POINTER(C.c_uint64)]),
     "gams_gpu_range_gc": (C.c_int, [_VP, _VP, C.c_uint32, C.c_int32, _VP, _VP, C.c_uint32, _VP]),
     "gams_gpu_range_gc_batch": (C.c_int, [_VP, _VP, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP]),
     "gams_index_create": (C.c_int, [_VP, C.c_uint32, _VP, _VP, _VP, _PP]),

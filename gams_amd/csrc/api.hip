@@ -80,6 +80,10 @@ void gams_gpu_destroy(gams_gpu_t *h) {
     }
     for (auto &e : h->rd_ev)
         if (e) (void)hipEventDestroy(e);
+    gams_pool_free(h, true, h->sw_text, h->sw_text_bytes);      // back to the pool, which is released below
+    gams_pool_free(h, true, h->sw_words, h->sw_words_bytes);
+    h->sw_text = nullptr;
+    h->sw_words = nullptr;
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (auto &slot : h->q_ev)

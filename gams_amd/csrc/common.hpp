@@ -54,6 +54,11 @@ struct gams_gpu {
     };
     std::vector<Block> dev_pool, pin_pool;
     std::vector<Block> host_blocks;   // page-locked blocks handed out by gams_gpu_host_alloc (their pooled sizes)
+    // gams_gpu_sw_text: the last call's text and words (total, flag, per-ctg offsets), page-locked, valid until the next call
+    char *sw_text = nullptr;
+    size_t sw_text_bytes = 0;
+    unsigned long long *sw_words = nullptr;
+    size_t sw_words_bytes = 0;
     // hipFuncAttributeMaxDynamicSharedMemorySize belongs to the kernel FUNCTION (per device), not to a plan:
     // the largest value any launch on this handle has asked for, per function; only ever raised (gams_lds_attr)
     // counts the launches that read a seqset (any stream of the handle): gams_seqset_upload_image queues the

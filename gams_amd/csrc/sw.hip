@@ -18,6 +18,8 @@
 
 #include "common.hpp"
 
+#include <string>
+
 #include <algorithm>
 
 struct gams_gcindex {
@@ -355,10 +357,300 @@ void gams_seqset_gcindex_free(gams_seqset_t *s) {
     s->gcindex = nullptr;
 }
 
+// ---- the rows as TSV text (sw.rs:152-190, the Display of Sw: data.rs:58-83) -------------------------------------
+// "sw:{feature id}:{serial}\t{chr}:{start}-{end}\t{M|L|R}\t{distance}\t{gc_content}\t{gc_mean}\t{gc_stddev}\t{gc_cv}\t\n"
+// (the last field, rg_count, is empty here as in `gams sw` without --rg).  The four floats are round(x, 4) values
+// (utils.rs:135-138, :161, :186): the f32 nearest to m / 10^4 for an integer m, and Rust's `{}` prints the shortest
+// digits that round-trip -- for m below 10^7 (values below 1000: gc values are below 1, cv a few units) that is m / 10^4
+// with its trailing zeros dropped, since no shorter decimal lies within half an ulp of it.  Anything else (a value of
+// 1000 or more, a negative coordinate) raises a flag and the host formats the batch as before.
+namespace {
+constexpr uint32_t kSwTextBlock = 512;     // rows per workgroup of the text kernels (256 threads x 2)
+constexpr uint32_t kSwTextStage = 49152;   // bytes of a block's text staged in LDS
+
+struct SwTextArgs {
+    const gams_sw_row_t *rows;
+    uint64_t n_rows;
+    const SwCtg *ctgs;
+    const uint64_t *ctg_row_off;       // [n_sel + 1]: first row of every selected ctg
+    uint32_t n_sel;
+    const uint64_t *feat_row_off;      // [nf + 1]: first row of every feature
+    const uint32_t *name_off;          // [n_sel + 1] into names
+    const char *names;
+    const uint32_t *id_off;            // [nf + 1] into ids
+    const char *ids;
+    uint32_t *len;                     // per row
+    uint32_t *blk_len;                 // per block
+    const unsigned long long *blk_off; // exclusive prefix, [nb] = all bytes
+    uint32_t nb;
+    char *text;
+    uint64_t text_cap;
+    unsigned long long *words;         // [0] = all bytes, [1] = flag (a value this formatter does not cover), [2 + k] = first byte of ctg k
+};
+
+__device__ __forceinline__ uint32_t sw_digits(uint32_t v) {
+    return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u
+         : v < 10000000u ? 7u : v < 100000000u ? 8u : v < 1000000000u ? 9u : 10u;
+}
+__device__ __forceinline__ char *sw_put_dec(char *p, uint32_t v) {
+    const uint32_t n = sw_digits(v);
+    char *e = p + n;
+    do {
+        *--e = (char)('0' + v % 10u);
+        v /= 10u;
+    } while (v);
+    return p + n;
+}
+// a round4 value as Rust prints it; returns the length (p == nullptr: length only); *bad set for values not covered
+__device__ __forceinline__ uint32_t sw_put_f4(char *p, float v, bool *bad) {
+    if (v != v) {
+        if (p) { p[0] = 'N'; p[1] = 'a'; p[2] = 'N'; }
+        return 3u;
+    }
+    if (!(v >= 0.0f) || !(v < 1000.0f)) {
+        *bad = true;
+        return 1u;
+    }
+    if (v == 0.0f && (__float_as_uint(v) >> 31)) {        // round(x, 4) of a tiny negative: Rust prints "-0"
+        if (p) { p[0] = '-'; p[1] = '0'; }
+        return 2u;
+    }
+    const uint32_t m = (uint32_t)((double)v * 10000.0 + 0.5);     // v is the f32 nearest to m / 10^4: exact in double
+    const uint32_t ip = m / 10000u;
+    uint32_t fr = m % 10000u, nd = 4u;
+    while (nd && fr % 10u == 0u) {
+        fr /= 10u;
+        --nd;
+    }
+    const uint32_t n = sw_digits(ip) + (nd ? 1u + nd : 0u);
+    if (p) {
+        p = sw_put_dec(p, ip);
+        if (nd) {
+            *p++ = '.';
+            char *e = p + nd;
+            for (uint32_t q = 0; q < nd; ++q) {
+                *--e = (char)('0' + fr % 10u);
+                fr /= 10u;
+            }
+        }
+    }
+    return n;
+}
+
+struct SwRowCtx {
+    uint32_t k, f, serial;    // selected ctg, feature (index into the call's arrays), 1-based row of the feature
+};
+__device__ __forceinline__ SwRowCtx sw_row_ctx(const SwTextArgs &a, uint64_t r, const gams_sw_row_t &w) {
+    uint32_t lo = 0, hi = a.n_sel;                       // last ctg whose first row <= r
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.ctg_row_off[mid] <= r)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    SwRowCtx c;
+    c.k = lo;
+    c.f = a.ctgs[lo].feat_first + w.feature;
+    c.serial = (uint32_t)(r - a.feat_row_off[c.f]) + 1u;    // sw.rs:148: the serial restarts with every feature
+    return c;
+}
+// the row's text at p (nullptr: its length only)
+__device__ __forceinline__ uint32_t sw_row_text(const SwTextArgs &a, uint64_t r, char *p, bool *bad) {
+    const gams_sw_row_t w = a.rows[r];
+    const SwRowCtx c = sw_row_ctx(a, r, w);
+    const uint32_t id0 = a.id_off[c.f], idn = a.id_off[c.f + 1u] - id0;
+    const uint32_t nm0 = a.name_off[c.k], nmn = a.name_off[c.k + 1u] - nm0;
+    if (w.start < 0 || w.end < 0 || w.distance < 0 || (uint32_t)w.type > 2u) *bad = true;
+    const uint32_t st = (uint32_t)w.start, en = (uint32_t)w.end, di = (uint32_t)w.distance;
+    if (!p) {
+        uint32_t n = 3u + idn + 1u + sw_digits(c.serial) + 1u + nmn + 1u + sw_digits(st);
+        if (en != st) n += 1u + sw_digits(en);
+        n += 1u + 1u + 1u + sw_digits(di) + 1u;
+        n += sw_put_f4(nullptr, w.gc_content, bad) + 1u + sw_put_f4(nullptr, w.gc_mean, bad) + 1u +
+             sw_put_f4(nullptr, w.gc_stddev, bad) + 1u + sw_put_f4(nullptr, w.gc_cv, bad) + 2u;
+        return n;
+    }
+    char *q = p;
+    *q++ = 's';
+    *q++ = 'w';
+    *q++ = ':';
+    for (uint32_t i = 0; i < idn; ++i) *q++ = a.ids[id0 + i];
+    *q++ = ':';
+    q = sw_put_dec(q, c.serial);
+    *q++ = '\t';
+    for (uint32_t i = 0; i < nmn; ++i) *q++ = a.names[nm0 + i];
+    *q++ = ':';
+    q = sw_put_dec(q, st);
+    if (en != st) {
+        *q++ = '-';
+        q = sw_put_dec(q, en);
+    }
+    *q++ = '\t';
+    *q++ = "MLR"[(uint32_t)w.type > 2u ? 0u : (uint32_t)w.type];
+    *q++ = '\t';
+    q = sw_put_dec(q, di);
+    *q++ = '\t';
+    q += sw_put_f4(q, w.gc_content, bad);
+    *q++ = '\t';
+    q += sw_put_f4(q, w.gc_mean, bad);
+    *q++ = '\t';
+    q += sw_put_f4(q, w.gc_stddev, bad);
+    *q++ = '\t';
+    q += sw_put_f4(q, w.gc_cv, bad);
+    *q++ = '\t';
+    *q++ = '\n';
+    return (uint32_t)(q - p);
+}
+
+__global__ __launch_bounds__(256) void sw_text_len_kernel(const SwTextArgs a) {
+    __shared__ uint32_t ws[4];
+    const uint64_t base = (uint64_t)blockIdx.x * kSwTextBlock;
+    const uint32_t tid = threadIdx.x;
+    uint32_t sum = 0;
+    bool bad = false;
+#pragma unroll
+    for (uint32_t u = 0; u < 2u; ++u) {
+        const uint64_t r = base + 2u * tid + u;
+        if (r >= a.n_rows) continue;
+        const uint32_t l = sw_row_text(a, r, nullptr, &bad);
+        a.len[r] = l;
+        sum += l;
+    }
+    if (bad) a.words[1] = 1ull;
+    for (int d = 32; d; d >>= 1) sum += (uint32_t)__shfl_xor((int)sum, d, 64);
+    if ((tid & 63u) == 0u) ws[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0u) a.blk_len[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// exclusive prefix of the blocks' byte counts (one workgroup), the total behind them
+__global__ __launch_bounds__(1024) void sw_text_scan_kernel(const uint32_t *blk_len, uint32_t nb, unsigned long long *blk_off,
+                                                            unsigned long long *words) {
+    __shared__ unsigned long long wsum[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t per = (nb + 1023u) / 1024u;
+    const uint32_t b0 = min(nb, tid * per), b1 = min(nb, b0 + per);
+    unsigned long long mine = 0;
+    for (uint32_t b = b0; b < b1; ++b) mine += blk_len[b];
+    const unsigned long long inc = wave_incl_scan_u64(mine);
+    if (lane == 63u) wsum[wv] = inc;
+    __syncthreads();
+    unsigned long long base = 0, all = 0;
+    for (uint32_t w = 0; w < 16u; ++w) {
+        if (w < wv) base += wsum[w];
+        all += wsum[w];
+    }
+    unsigned long long off = base + inc - mine;
+    for (uint32_t b = b0; b < b1; ++b) {
+        blk_off[b] = off;
+        off += blk_len[b];
+    }
+    if (tid == 0u) {
+        blk_off[nb] = all;
+        words[0] = all;
+    }
+}
+
+__global__ __launch_bounds__(256) void sw_text_write_kernel(const SwTextArgs a) {
+    __shared__ uint32_t scr[4];
+    __shared__ __align__(16) char stage[kSwTextStage + 16];
+    const uint64_t base = (uint64_t)blockIdx.x * kSwTextBlock;
+    const uint32_t tid = threadIdx.x;
+    uint32_t l[2], mine = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < 2u; ++u) {
+        const uint64_t r = base + 2u * tid + u;
+        l[u] = r < a.n_rows ? a.len[r] : 0u;
+        mine += l[u];
+    }
+    uint32_t tot;
+    const uint32_t rel = block_excl_scan_256<uint32_t>(mine, scr, tot);
+    const uint64_t blk0 = a.blk_off[blockIdx.x];
+    const uint32_t mis = (uint32_t)(blk0 & 15u);
+    const bool fits = blk0 + tot <= a.text_cap;
+    const bool staged = tot <= kSwTextStage && fits;
+    uint32_t at = rel;
+    bool bad = false;
+#pragma unroll
+    for (uint32_t u = 0; u < 2u; ++u) {
+        const uint64_t r = base + 2u * tid + u;
+        if (r >= a.n_rows) break;
+        if (staged)
+            (void)sw_row_text(a, r, stage + mis + at, &bad);
+        else if (fits)
+            (void)sw_row_text(a, r, a.text + blk0 + at, &bad);
+        at += l[u];
+    }
+    if (!staged) return;
+    __syncthreads();
+    const uint32_t head = min(tot, (16u - mis) & 15u);
+    char *const dst = a.text + blk0;
+    if (tid < head) dst[tid] = stage[mis + tid];
+    const uint32_t units = (tot - head) >> 4;
+    const uint4 *const su = reinterpret_cast<const uint4 *>(stage + mis + head);
+    uint4 *const du = reinterpret_cast<uint4 *>(dst + head);
+    for (uint32_t q = tid; q < units; q += 256u) du[q] = su[q];
+    const uint32_t done = head + (units << 4);
+    if (tid < tot - done) dst[done + tid] = stage[mis + done + tid];
+}
+
+// where every selected ctg's text begins: the bytes of the rows in front of its first row
+__global__ __launch_bounds__(64) void sw_text_ctg_kernel(const SwTextArgs a) {
+    const uint32_t k = blockIdx.x, lane = threadIdx.x;
+    if (k > a.n_sel) return;
+    const uint64_t r = a.ctg_row_off[k];                 // (entry n_sel = all rows)
+    const uint64_t b = r / kSwTextBlock;
+    unsigned long long off = 0;
+    for (uint64_t q = b * kSwTextBlock + lane; q < r; q += 64u) off += a.len[q];
+    for (int d = 32; d; d >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)off, d, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(off >> 32), d, 64);
+        off += ((unsigned long long)hi << 32) | lo;
+    }
+    if (lane == 0) a.words[2u + k] = (b < a.nb ? a.blk_off[b] : a.blk_off[a.nb]) + off;
+}
+
+struct SwTextReq {                       // what gams_gpu_sw_text adds to a batch call
+    const char *const *chr;              // per selected ctg
+    const char *const *feat_id;          // per feature
+    const char **text;
+    uint64_t *text_bytes;
+    const uint64_t **ctg_off;
+};
+}  // namespace
+
+static int sw_batch_impl(gams_gpu_t *h, gams_seqset_t *s, uint32_t n_sel, const uint32_t *ctg_index,
+                         const int32_t *chr_start, const uint64_t *feat_off, const int32_t *feat_start,
+                         const int32_t *feat_end, int32_t size, int32_t max, int32_t resize, gams_sw_row_t *rows,
+                         uint64_t cap, uint64_t *row_off, uint64_t *n_rows, const SwTextReq *tx);
+
 extern "C" int gams_gpu_sw_batch(gams_gpu_t *h, gams_seqset_t *s, uint32_t n_sel, const uint32_t *ctg_index,
                                  const int32_t *chr_start, const uint64_t *feat_off, const int32_t *feat_start,
                                  const int32_t *feat_end, int32_t size, int32_t max, int32_t resize,
                                  gams_sw_row_t *rows, uint64_t cap, uint64_t *row_off, uint64_t *n_rows) {
+    return sw_batch_impl(h, s, n_sel, ctg_index, chr_start, feat_off, feat_start, feat_end, size, max, resize, rows, cap,
+                         row_off, n_rows, nullptr);
+}
+
+extern "C" int gams_gpu_sw_text(gams_gpu_t *h, gams_seqset_t *s, uint32_t n_sel, const uint32_t *ctg_index,
+                                const char *const *chr, const int32_t *chr_start, const uint64_t *feat_off,
+                                const int32_t *feat_start, const int32_t *feat_end, const char *const *feat_id,
+                                int32_t size, int32_t max, int32_t resize, const char **text, uint64_t *text_bytes,
+                                const uint64_t **ctg_off, uint64_t *n_rows) {
+    if (!h || !text || !text_bytes || !n_rows || (n_sel && (!chr || !feat_off)))
+        return gams_fail(h, GAMS_EINVAL, "gpu_sw_text: null argument");
+    if (n_sel && feat_off[n_sel] && !feat_id) return gams_fail(h, GAMS_EINVAL, "gpu_sw_text: null feature ids");
+    const SwTextReq tx{chr, feat_id, text, text_bytes, ctg_off};
+    *text = nullptr;
+    *text_bytes = 0;
+    return sw_batch_impl(h, s, n_sel, ctg_index, chr_start, feat_off, feat_start, feat_end, size, max, resize, nullptr, 0,
+                         nullptr, n_rows, &tx);
+}
+
+static int sw_batch_impl(gams_gpu_t *h, gams_seqset_t *s, uint32_t n_sel, const uint32_t *ctg_index,
+                         const int32_t *chr_start, const uint64_t *feat_off, const int32_t *feat_start,
+                         const int32_t *feat_end, int32_t size, int32_t max, int32_t resize, gams_sw_row_t *rows,
+                         uint64_t cap, uint64_t *row_off, uint64_t *n_rows, const SwTextReq *tx) {
     if (!h || !s || !n_rows || (n_sel && (!ctg_index || !chr_start || !feat_off)))
         return gams_fail(h, GAMS_EINVAL, "gpu_sw: null argument");
     // size or resize 1: half_resize = 0 makes center_resize slice [mid+1, mid-1] (window.rs:113-123),
@@ -394,7 +686,8 @@ extern "C" int gams_gpu_sw_batch(gams_gpu_t *h, gams_seqset_t *s, uint32_t n_sel
     const size_t b_i32 = ((size_t)nf * sizeof(int32_t) + 255) & ~(size_t)255;
     const size_t b_off = (((size_t)nf + 1) * sizeof(uint64_t) + 255) & ~(size_t)255;
     const size_t in_bytes = b_ctg + 3 * b_i32 + b_off;
-    const bool size_query = !rows || cap == 0;
+    const bool size_query = !tx && (!rows || cap == 0);
+    std::vector<uint64_t> crow((size_t)n_sel + 1, 0);    // first row of every selected ctg (text mode)
     uint8_t *pin = nullptr, *dev = nullptr;
     size_t pin_cap = 0, dev_cap = 0;
     std::vector<uint64_t> off_host;                 // size query: no device, no pinned memory
@@ -423,6 +716,7 @@ extern "C" int gams_gpu_sw_batch(gams_gpu_t *h, gams_seqset_t *s, uint32_t n_sel
         const uint32_t i = ctg_index[k];
         const int32_t cs = chr_start[k], ce = cs + (int32_t)s->len[i] - 1;
         if (row_off) row_off[k] = tot;
+        crow[k] = tot;
         if (cg) cg[k] = SwCtg{s->off[i], s->len[i], cs, ce, (uint32_t)feat_off[k], {0u, 0u}};
         for (uint64_t f = feat_off[k]; f < feat_off[k + 1]; ++f) {
             // window.rs:98-110: the middle pair of the feature must be members of the ctg span --
@@ -448,8 +742,10 @@ extern "C" int gams_gpu_sw_batch(gams_gpu_t *h, gams_seqset_t *s, uint32_t n_sel
     }
     off[nf] = tot;
     if (row_off) row_off[n_sel] = tot;
+    crow[n_sel] = tot;
     *n_rows = tot;
     if (size_query) return GAMS_OK;
+    if (tx) cap = tot;                                   // text mode: every row, kept on the device
 
     int rc = gams_seqset_gcindex(h, s);
     if (rc != GAMS_OK) {
@@ -494,6 +790,132 @@ extern "C" int gams_gpu_sw_batch(gams_gpu_t *h, gams_seqset_t *s, uint32_t n_sel
     SW_HIP(hipEventRecord(h->k1, h->compute));
     h->k_valid = true;
     h->kq_used = 0;
+    if (tx) {
+        // ---- rows -> TSV text on the device ----------------------------------------------------------------------
+        std::vector<uint32_t> name_off((size_t)n_sel + 1), id_off((size_t)nf + 1);
+        std::string names, ids;
+        size_t max_name = 0, max_id = 0;
+        for (uint32_t k = 0; k < n_sel; ++k) {
+            name_off[k] = (uint32_t)names.size();
+            if (!tx->chr[k]) {
+                (void)hipStreamSynchronize(h->compute);
+                release();
+                return gams_fail(h, GAMS_EINVAL, "gpu_sw_text: null chromosome name");
+            }
+            const size_t before = names.size();
+            names += tx->chr[k];
+            max_name = std::max(max_name, names.size() - before);
+        }
+        name_off[n_sel] = (uint32_t)names.size();
+        for (uint32_t f = 0; f < nf; ++f) {
+            id_off[f] = (uint32_t)ids.size();
+            if (!tx->feat_id[f] || ids.size() > 0xF0000000ull) {
+                (void)hipStreamSynchronize(h->compute);
+                release();
+                return gams_fail(h, GAMS_EINVAL, "gpu_sw_text: null feature id, or more than 4 GB of ids");
+            }
+            const size_t before = ids.size();
+            ids += tx->feat_id[f];
+            max_id = std::max(max_id, ids.size() - before);
+        }
+        id_off[nf] = (uint32_t)ids.size();
+        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const uint32_t nb = (uint32_t)((n_out + kSwTextBlock - 1) / kSwTextBlock);
+        const size_t t_crow = al(((size_t)n_sel + 1) * 8), t_noff = al(((size_t)n_sel + 1) * 4), t_names = al(names.size() + 1),
+                     t_ioff = al(((size_t)nf + 1) * 4), t_ids = al(ids.size() + 1);
+        const size_t tab_bytes = t_crow + t_noff + t_names + t_ioff + t_ids;
+        const size_t b_len = al((size_t)std::max<uint64_t>(n_out, 1) * 4), b_blen = al((size_t)std::max(nb, 1u) * 4),
+                     b_boff = al(((size_t)nb + 1) * 8), b_words = al(((size_t)n_sel + 3) * 8);
+        const uint64_t text_cap = std::max<uint64_t>(n_out * (uint64_t)(max_id + max_name + 96), 4096);
+        uint8_t *tpin = nullptr, *tdev = nullptr;
+        size_t tpin_cap = 0, tdev_cap = 0;
+        auto release_text = [&]() {
+            if (tpin) gams_pool_free(h, true, tpin, tpin_cap);
+            if (tdev) gams_pool_free(h, false, tdev, tdev_cap);
+        };
+#define SWT_HIP(call)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            (void)hipStreamSynchronize(h->compute);                                    \
+            release_text();                                                            \
+            release();                                                                 \
+            return gams_fail(h, e_ == hipErrorOutOfMemory ? GAMS_ENOMEM : GAMS_EHIP,   \
+                             std::string(#call) + ": " + hipGetErrorString(e_));       \
+        }                                                                              \
+    } while (0)
+        SWT_HIP(gams_pool_alloc(h, true, tab_bytes, reinterpret_cast<void **>(&tpin), &tpin_cap));
+        SWT_HIP(gams_pool_alloc(h, false, tab_bytes + b_len + b_blen + b_boff + b_words + al(text_cap),
+                                reinterpret_cast<void **>(&tdev), &tdev_cap));
+        std::memcpy(tpin, crow.data(), crow.size() * 8);
+        std::memcpy(tpin + t_crow, name_off.data(), name_off.size() * 4);
+        std::memcpy(tpin + t_crow + t_noff, names.data(), names.size());
+        std::memcpy(tpin + t_crow + t_noff + t_names, id_off.data(), id_off.size() * 4);
+        std::memcpy(tpin + t_crow + t_noff + t_names + t_ioff, ids.data(), ids.size());
+        SWT_HIP(hipMemcpyAsync(tdev, tpin, tab_bytes, hipMemcpyHostToDevice, h->compute));
+        SwTextArgs ta{};
+        ta.rows = d_rows;
+        ta.n_rows = n_out;
+        ta.ctgs = a.ctgs;
+        ta.ctg_row_off = reinterpret_cast<const uint64_t *>(tdev);
+        ta.n_sel = n_sel;
+        ta.feat_row_off = a.row_off;
+        ta.name_off = reinterpret_cast<const uint32_t *>(tdev + t_crow);
+        ta.names = reinterpret_cast<const char *>(tdev + t_crow + t_noff);
+        ta.id_off = reinterpret_cast<const uint32_t *>(tdev + t_crow + t_noff + t_names);
+        ta.ids = reinterpret_cast<const char *>(tdev + t_crow + t_noff + t_names + t_ioff);
+        uint8_t *q = tdev + tab_bytes;
+        ta.len = reinterpret_cast<uint32_t *>(q);
+        ta.blk_len = reinterpret_cast<uint32_t *>(q + b_len);
+        unsigned long long *blk_off = reinterpret_cast<unsigned long long *>(q + b_len + b_blen);
+        ta.blk_off = blk_off;
+        ta.nb = nb;
+        ta.words = reinterpret_cast<unsigned long long *>(q + b_len + b_blen + b_boff);
+        ta.text = reinterpret_cast<char *>(q + b_len + b_blen + b_boff + b_words);
+        ta.text_cap = text_cap;
+        SWT_HIP(hipMemsetAsync(ta.words, 0, b_words, h->compute));
+        if (nb) {
+            hipLaunchKernelGGL(sw_text_len_kernel, dim3(nb), dim3(256), 0, h->compute, ta);
+            hipLaunchKernelGGL(sw_text_scan_kernel, dim3(1), dim3(1024), 0, h->compute, ta.blk_len, nb, blk_off, ta.words);
+            hipLaunchKernelGGL(sw_text_write_kernel, dim3(nb), dim3(256), 0, h->compute, ta);
+            hipLaunchKernelGGL(sw_text_ctg_kernel, dim3(n_sel + 1), dim3(64), 0, h->compute, ta);
+            SWT_HIP(hipGetLastError());
+        }
+        // the words first (total, flag, per-ctg offsets), then the text -- whose size they say -- into the handle's
+        // page-locked text buffer, valid until the next call
+        const size_t n_words = (size_t)n_sel + 3;
+        if (h->sw_words_bytes < n_words * 8) {
+            gams_pool_free(h, true, h->sw_words, h->sw_words_bytes);
+            h->sw_words = nullptr;
+            h->sw_words_bytes = 0;
+            SWT_HIP(gams_pool_alloc(h, true, n_words * 8, reinterpret_cast<void **>(&h->sw_words), &h->sw_words_bytes));
+        }
+        SWT_HIP(hipMemcpyAsync(h->sw_words, ta.words, n_words * 8, hipMemcpyDeviceToHost, h->compute));
+        SWT_HIP(hipStreamSynchronize(h->compute));
+        const uint64_t bytes = h->sw_words[0];
+        if (h->sw_words[1] != 0 || bytes > text_cap) {
+            release_text();
+            release();
+            return gams_fail(h, GAMS_EUNSUPPORTED,
+                             "gpu_sw_text: a value this formatter does not cover (a statistic of 1000 or more, a negative "
+                             "coordinate): format gams_gpu_sw_batch's rows on the host");
+        }
+        if (h->sw_text_bytes < bytes) {
+            gams_pool_free(h, true, h->sw_text, h->sw_text_bytes);
+            h->sw_text = nullptr;
+            h->sw_text_bytes = 0;
+            SWT_HIP(gams_pool_alloc(h, true, bytes + bytes / 8 + 4096, reinterpret_cast<void **>(&h->sw_text), &h->sw_text_bytes));
+        }
+        if (bytes) SWT_HIP(hipMemcpyAsync(h->sw_text, ta.text, bytes, hipMemcpyDeviceToHost, h->compute));
+        SWT_HIP(hipStreamSynchronize(h->compute));
+#undef SWT_HIP
+        *tx->text = bytes ? h->sw_text : nullptr;
+        *tx->text_bytes = bytes;
+        if (tx->ctg_off) *tx->ctg_off = reinterpret_cast<const uint64_t *>(h->sw_words + 2);
+        release_text();
+        release();
+        return GAMS_OK;
+    }
     SW_HIP(hipMemcpyAsync(rows, d_rows, n_out * sizeof(gams_sw_row_t), hipMemcpyDeviceToHost, h->compute));
     SW_HIP(hipStreamSynchronize(h->compute));
 #undef SW_HIP

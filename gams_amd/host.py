@@ -74,6 +74,9 @@ def load():
     L.gams_host_count_multi.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p]
     L.gams_host_cover_multi.restype = C.c_int
     L.gams_host_cover_multi.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 8 + [C.c_uint64, C.c_void_p]
+    L.gams_host_sw_multi_timed.restype = C.c_void_p
+    L.gams_host_sw_multi_timed.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, sp, sp, ip, ip, C.c_void_p, C.c_char_p,
+                                           C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.gams_host_sw_multi.restype = C.c_void_p
     L.gams_host_sw_multi.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, sp, sp, ip, ip, C.c_void_p, C.c_char_p,
                                      C.c_int32, C.c_int32, C.c_int32]
@@ -315,6 +318,22 @@ def sw_multi(engines, ctgs, features_per_ctg, size=100, mx=20, resize=500):
                                            rows.encode(), size, mx, resize))
 
 
+def sw_multi_timed(engines, ctgs, features_per_ctg, size=100, mx=20, resize=500):
+    """sw_multi, returning (text, ms of the operator itself: upload + kernels + row text, without this binding's
+    parsing and copies)."""
+    n, ids, chrs, st, en = _ctg_arrays(ctgs)
+    bufs = [np.ascontiguousarray(np.frombuffer(c["seq"], np.uint8) if not isinstance(c["seq"], np.ndarray)
+                                 else c["seq"]) for c in ctgs]
+    seqs = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in bufs])
+    hs = (C.c_void_p * len(engines))(*[e.h.value for e in engines])
+    rows = "\n".join(f"{i}\t{fid}\t{s}\t{e}" for i, fl in enumerate(features_per_ctg) for fid, s, e in fl)
+    ms = C.c_double(0.0)
+    n_out = C.c_uint64(0)
+    p = load().gams_host_sw_multi_timed(hs, len(engines), n, ids, chrs, st.ctypes.data, en.ctypes.data, seqs,
+                                        rows.encode(), size, mx, resize, C.byref(ms), C.byref(n_out))
+    return _take_bytes(p, n_out).decode(), ms.value
+
+
 def _check_rc(rc):
     if rc != 0:
         L = load()
@@ -405,14 +424,6 @@ def range_roundtrip(s):
 
 
 # ---- wire formats either side of the path (gams_wire.cpp; SURVEY 8 f-3, parity unpinned) --------
-def _take_bytes(p, n):
-    if not p:
-        raise HostError(load().gams_host_last_code(), load().gams_host_last_error().decode(errors="replace"))
-    out = C.string_at(p, n.value)
-    load().gams_host_free(p)
-    return out
-
-
 def bincode_ctg_bundle(ctgs):
     """bundle:ctg:{chr}: bincode 1.3.3 of BTreeMap<String, Ctg> (redis.rs:216-233)"""
     n, ids, chrs, st, en = _ctg_arrays(ctgs)

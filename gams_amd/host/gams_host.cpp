@@ -918,6 +918,27 @@ std::vector<std::string> sw_proc_ctgs(gams_gpu_t *h, const std::vector<Ctg> &ctg
         check(h, gams_seqset_upload_all(h, sg.s, ptrs.data()));
         std::vector<uint64_t> row_off(n + 1, 0);
         uint64_t nrows = 0;
+        {
+            // the rows' text straight from the device (gams_gpu_sw_text); values it does not cover send the batch
+            // down the host formatter below
+            std::vector<const char *> chr(n), ids(feat_off[n]);
+            for (uint32_t k = 0; k < n; ++k) {
+                chr[k] = ctgs[todo[b + k]].chr_id.c_str();
+                const std::vector<Feature> &fv = features[todo[b + k]];
+                for (size_t f = 0; f < fv.size(); ++f) ids[feat_off[k] + f] = fv[f].id.c_str();
+            }
+            const char *text = nullptr;
+            uint64_t tbytes = 0;
+            const uint64_t *toff = nullptr;
+            const int rc = gams_gpu_sw_text(h, sg.s, n, index.data(), chr.data(), chr_start.data(), feat_off.data(), fs.data(),
+                                            fe.data(), ids.data(), a.size, a.max, a.resize, &text, &tbytes, &toff, &nrows);
+            if (rc == GAMS_OK) {
+                for (uint32_t k = 0; k < n; ++k) out[todo[b + k]].assign(text + toff[k], text + toff[k + 1]);
+                b = e;
+                continue;
+            }
+            if (rc != GAMS_EUNSUPPORTED) check(h, rc);
+        }
         check(h, gams_gpu_sw_batch(h, sg.s, n, index.data(), chr_start.data(), feat_off.data(), fs.data(), fe.data(),
                                    a.size, a.max, a.resize, nullptr, 0, row_off.data(), &nrows));
         // rows land in page-locked memory: the readback runs at the rate of the link

@@ -1,6 +1,7 @@
 // gams_host_c.cpp -- flat C entry points of the host layer, for tests (ctypes) and for a
 // non-C++ host.  Strings returned are malloc'd: release with gams_host_free.  On error the
 // functions return NULL and gams_host_last_error() has the message.
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
@@ -271,6 +272,42 @@ char *gams_host_sw_multi(gams_gpu_t *const *handles, uint32_t n_handles, uint32_
                                                 make_ctgs(n, ids, chrs, starts, ends),
                                                 std::vector<const uint8_t *>(seqs, seqs + n), f, a))
             out += s;
+        return out;
+    });
+}
+
+// the same, also reporting the milliseconds of the operator itself (gams::sw_proc_ctgs_multi: upload, kernels, text;
+// without the parsing of `features` in front and the concatenation behind, which belong to this wrapper)
+char *gams_host_sw_multi_timed(gams_gpu_t *const *handles, uint32_t n_handles, uint32_t n, const char *const *ids,
+                               const char *const *chrs, const int32_t *starts, const int32_t *ends,
+                               const uint8_t *const *seqs, const char *features, int32_t size, int32_t max, int32_t resize,
+                               double *operator_ms, uint64_t *out_len) {
+    return guarded_bytes(out_len, [&] {
+        std::vector<std::vector<gams::Feature>> f(n);
+        for (const std::string &ln : split_lines(features)) {
+            std::istringstream is(ln);
+            std::string ci, id, s0, s1;
+            std::getline(is, ci, '\t');
+            std::getline(is, id, '\t');
+            std::getline(is, s0, '\t');
+            std::getline(is, s1, '\t');
+            f.at((size_t)std::stoul(ci)).push_back(gams::Feature{id, std::stoi(s0), std::stoi(s1)});
+        }
+        gams::SwArgs a;
+        a.size = size;
+        a.max = max;
+        a.resize = resize;
+        const std::vector<gams::Ctg> cv = make_ctgs(n, ids, chrs, starts, ends);
+        const std::vector<const uint8_t *> sv(seqs, seqs + n);
+        const std::vector<gams_gpu_t *> hv(handles, handles + n_handles);
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<std::string> rows = gams::sw_proc_ctgs_multi(hv, cv, sv, f, a);
+        if (operator_ms) *operator_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        size_t total = 0;
+        for (auto &s : rows) total += s.size();
+        std::string out;
+        out.reserve(total);
+        for (auto &s : rows) out += s;
         return out;
     });
 }

@@ -14,7 +14,7 @@
  * Reference interfaces replaced (paths under wang-q/gams @ 2024-10-22):
  *   gams_gpu_wave*            src/cmd_gams/wave.rs:138-155  (sliding + gc_content + thresholding_algo)
  *                             = src/libs/window.rs:78-94, bio gc_content, src/libs/stat.rs:16-56
- *   gams_gpu_sw(_batch)       src/cmd_gams/sw.rs:141-184    (center_sw + cache_gc_content + cache_gc_stat)
+ *   gams_gpu_sw(_batch, _text) src/cmd_gams/sw.rs:141-184   (center_sw + cache_gc_content + cache_gc_stat; _text: + the rows' text, :152-190)
  *                             = src/libs/window.rs:3-56,96-124, src/libs/utils.rs:141-213
  *   gams_gpu_count            src/libs/utils.rs:24-36       (count_rg -> Lapper::count)
  *   gams_gpu_locate           src/libs/utils.rs:7-22        (find_one_idx -> Lapper::find().next())
@@ -222,6 +222,21 @@ int gams_gpu_sw_batch(gams_gpu_t *h, gams_seqset_t *s, uint32_t n_sel, const uin
                       const int32_t *chr_start, const uint64_t *feat_off, const int32_t *feat_start,
                       const int32_t *feat_end, int32_t size, int32_t max, int32_t resize,
                       gams_sw_row_t *rows, uint64_t cap, uint64_t *row_off, uint64_t *n_rows);
+
+/* The rows of gams_gpu_sw_batch as the TSV text of `gams sw` (sw.rs:152-190 and the Display of Sw, data.rs:58-83:
+ * "sw:{feature id}:{serial}\t{chr}:{start}-{end}\t{M|L|R}\t{distance}\t{gc_content}\t{gc_mean}\t{gc_stddev}\t{gc_cv}\t\n",
+ * the last field -- rg_count -- empty), formatted on the device.  chr[k] = chromosome name of selected ctg k,
+ * feat_id[f] = id of feature f ("feature:{ctg}:{serial}", feature.rs:81-83), both NUL-terminated.  *text
+ * (text_bytes bytes, no header, no NUL) and *ctg_off (n_sel + 1 offsets: the rows of selected ctg k are
+ * text[ctg_off[k] .. ctg_off[k+1])) point into page-locked memory owned by the handle, valid until the handle's next
+ * gams_gpu_sw_text.  GAMS_EUNSUPPORTED if a statistic is 1000 or more or a coordinate negative (the formatter
+ * prints the four round4 values as m / 10^4 with the trailing zeros dropped, which is what Rust's `{}` prints for them
+ * below 1000): format the rows of gams_gpu_sw_batch on the host then. */
+int gams_gpu_sw_text(gams_gpu_t *h, gams_seqset_t *s, uint32_t n_sel, const uint32_t *ctg_index,
+                     const char *const *chr, const int32_t *chr_start, const uint64_t *feat_off,
+                     const int32_t *feat_start, const int32_t *feat_end, const char *const *feat_id,
+                     int32_t size, int32_t max, int32_t resize, const char **text, uint64_t *text_bytes,
+                     const uint64_t **ctg_off, uint64_t *n_rows);
 
 /* gc_content (round4, utils.rs:141-162) of n chromosome ranges inside ctg i: what `gams peak`
  * asks per merged peak (peak.rs:79; second "next" row of SURVEY section 8f). */

@@ -663,3 +663,53 @@ def test_device_rows_of_several_plans_in_flight(eng, s288c):
         p.close()
     for s in sets:
         s.close()
+
+
+def test_sw_text_from_the_device_equals_the_host_formatter(eng, s288c):
+    """gams_gpu_sw_text (rows formatted on the device: the four round4 values printed as m / 10^4 without trailing
+    zeros, which is what Rust's `{}` prints for them) against the oracle's text of sw.rs:152-190 and against the host
+    formatter over gams_gpu_sw's rows: features at ctg edges (few windows), resize == size (one window per statistic:
+    stddev is NaN, cv NaN), long and odd names, ctgs without features, the per-ctg offsets."""
+    import ctypes as C
+
+    rng = np.random.default_rng(21)
+    ctgs = all_ctgs(s288c, piece=40000)[:6]
+    ctgs[2] = dict(ctgs[2], chr_id="chr_with-a.long_name")
+    ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])
+    for size, mx, resize in ((100, 20, 500), (100, 3, 100), (50, 40, 1000), (7, 2, 7)):
+        sel, chr_names, cst, foff, fs, fe, ids, feats_per = [], [], [], [0], [], [], [], []
+        for i, c in enumerate(ctgs):
+            n = 0 if i == 3 else int(rng.integers(1, 40))
+            a = np.sort(rng.integers(c["chr_start"], c["chr_end"] + 1, n))
+            a[:2] = [c["chr_start"], c["chr_end"]][:n]                      # features on the ctg's first / last base
+            b = np.minimum(a + rng.choice([0, 1, 30, 600], n), c["chr_end"])
+            feats = [(f"feature:{c['id']}:{j + 1}", int(x), int(y)) for j, (x, y) in enumerate(zip(a, b))]
+            feats_per.append(feats)
+            sel.append(i)
+            chr_names.append(c["chr_id"].encode())
+            cst.append(c["chr_start"])
+            foff.append(foff[-1] + n)
+            fs += [f[1] for f in feats]
+            fe += [f[2] for f in feats]
+            ids += [f[0].encode() for f in feats]
+        sel_a, cst_a, foff_a = np.array(sel, np.uint32), np.array(cst, np.int32), np.array(foff, np.uint64)
+        fs_a, fe_a = np.array(fs, np.int32), np.array(fe, np.int32)
+        names = (C.c_char_p * len(sel))(*chr_names)
+        idp = (C.c_char_p * max(len(ids), 1))(*ids)
+        txt, nb, off, nrows = C.c_void_p(), C.c_uint64(), C.c_void_p(), C.c_uint64()
+        eng.check(eng.lib.gams_gpu_sw_text(eng.h, ss.p, len(sel), sel_a.ctypes.data, names, cst_a.ctypes.data, foff_a.ctypes.data,
+                                           fs_a.ctypes.data, fe_a.ctypes.data, idp, size, mx, resize, C.byref(txt), C.byref(nb),
+                                           C.byref(off), C.byref(nrows)))
+        text = C.string_at(txt.value, nb.value).decode()
+        offs = np.frombuffer((C.c_uint64 * (len(sel) + 1)).from_address(off.value), np.uint64)
+        assert int(offs[0]) == 0 and int(offs[-1]) == nb.value and text.count("\n") == nrows.value
+        for k, c in enumerate(ctgs):
+            mine = text[int(offs[k]):int(offs[k + 1])]
+            exp = ora.sw_proc_ctg(c["chr_id"], c["chr_start"], c["chr_end"], c["seq"], feats_per[k], size, mx, resize) \
+                if feats_per[k] else ""
+            assert mine == exp, (size, mx, resize, k)
+            if feats_per[k]:
+                assert mine == host.sw(eng, c, feats_per[k], size, mx, resize)        # gams_gpu_sw + the host formatter
+        if resize == size:
+            assert "NaN" in text
+    ss.close()

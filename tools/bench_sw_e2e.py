@@ -41,3 +41,10 @@ for rep in range(3):
     rows = out.count("\n")
     print(f"sw end to end, batched: {rows} rows ({len(out) / 1e6:.0f} MB of text) in {dt * 1e3:.0f} ms -> "
           f"{rows / dt / 1e6:.2f} M rows/s", flush=True)
+
+# the operator's own time (upload + kernels + row text), without this binding's feature parsing and string copies
+for rep in range(3):
+    out, ms = host.sw_multi_timed([eng], ctgs, flist)
+    rows = out.count("\n")
+    print(f"sw operator time: {rows} rows ({len(out) / 1e6:.0f} MB of text) in {ms:.1f} ms -> {rows / ms / 1e3:.2f} M rows/s",
+          flush=True)
