@@ -149,6 +149,8 @@ struct gams_wave_plan {
     size_t h_peaks_bytes = 0;
     uint32_t tile_cap = 0, tile_cap_req = 0;
     uint32_t tw_req = 0;                        // gams_wave_plan_set_tile request (0: the library's choice)
+    uint32_t nth = 256;                         // threads per workgroup of the tile kernel (64 / 128: step-1 kernels, W = 28)
+    uint32_t nth_req = 0;                       // gams_wave_plan_set_threads request (0: the library's choice)
     gams_peak_t *d_dense = nullptr;             // packed copy made by gams_wave_peaks
     uint64_t dense_cap = 0;
     uint64_t run_idx = 0;
@@ -250,13 +252,13 @@ int wave_baked_kind(const gams_wave_params_t &q, int w) {
 }
 bool wave_is_baked(const gams_wave_params_t &q, int w) { return wave_baked_kind(q, w) != 0; }
 
-size_t wave_fast_lds_bytes(uint32_t max_chunks, uint32_t w, uint32_t lag, bool dense) {
+size_t wave_fast_lds_bytes(uint32_t max_chunks, uint32_t w, uint32_t lag, bool dense, uint32_t nth = 256) {
     size_t b = (size_t)((((max_chunks + 8u) >> 1) + 16u + 3u) & ~3u) * 4;   // BM: 16 mask bits per chunk + pad
     b += 16 * 4;                                         // scratch
-    b += (256u * w + lag + 1u + 31u) & ~15u;             // K (threads past the tile's end still read their slots)
-    b += 272 * 8;                                        // PS: block sums of the baked kernels
-    b += 256 * 2;                                        // RK: ranks of phase 4b
-    if (dense) b += ((256u * w + 15u) & ~15u) + 16u;     // SG (+ the dword behind the last group, read with it)
+    b += (nth * w + lag + 1u + 31u) & ~15u;              // K (threads past the tile's end still read their slots)
+    b += (nth + 16) * 8;                                 // PS: block sums of the baked kernels
+    b += nth * 2;                                        // RK: ranks of phase 4b
+    if (dense) b += ((nth * w + 15u) & ~15u) + 16u;      // SG (+ the dword behind the last group, read with it)
     return (b + 15) & ~(size_t)15;
 }
 
@@ -329,7 +331,13 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
             const uint64_t tiles = p->total_windows / tw;
             const bool step1 = q.size == 100 && q.step == 1 && q.lag == 100;   // baked W = 20 fits 64 VGPRs
             const bool flight = p->depth >= 2;
-            if (pick == 0 && w == 28 && (step1 || (q.size == 100 && q.step == 1 && wave_baked_kind(q, 28) == 2)) && tiles >= 4096)
+            // (round 3: W = 28 tiles of ONE wave -- 64 threads, 1,691 windows at lag 100 -- from 4,096 such tiles on:
+            // 384 Mb 325 -> 285 us, 120 Mb 112 -> 100 us, 12 Mb 21.9 (W = 20) -> 21.2 us; gpurun_out/r3_ab_threads*.log)
+            const bool s1w28 = step1 || (q.size == 100 && q.step == 1 && wave_baked_kind(q, 28) == 2);
+            if (pick == 0 && w == 28 && s1w28 && p->nth_req == 0 && q.lag + 1u <= 32u * 28u &&
+                p->total_windows / (64u * 28u) >= 4096)
+                pick = w;
+            if (pick == 0 && w == 28 && s1w28 && tiles >= 4096)
                 pick = w;
             if (pick == 0 && w == 20 && (step1 || (q.size == 100 && q.step == 1 && wave_baked_kind(q, 20) == 2)) && tiles >= 1024)
                 pick = w;
@@ -344,15 +352,22 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
         }
         if (pick) {
             p->fast_w = pick;
-            // baked kernels: the tile's windows plus the lag+1 in front fill 256*W slots exactly
-            p->tw = wave_is_baked(q, pick) ? 256u * pick - q.lag - 1u : 256u * pick;
+            // step-1 W = 28 kernels: a tile per one or two waves instead of four (see wave_fast_tile's NTH), while at
+            // least half of the tile's slots stay windows
+            p->nth = 256;
+            if (pick == 28 && q.step == 1 && wave_is_baked(q, pick)) {
+                const uint32_t want = p->nth_req == 0 ? 64u : p->nth_req;       // the library's choice: one wave per tile
+                if ((want == 64 || want == 128) && q.lag + 1u <= (want / 2u) * 28u) p->nth = want;
+            }
+            // baked kernels: the tile's windows plus the lag+1 in front fill nth*W slots exactly
+            p->tw = wave_is_baked(q, pick) ? p->nth * pick - q.lag - 1u : 256u * pick;
             p->max_win = p->tw + q.lag + 1;
-            // rounded up to whole 256-chunk rows: the baked kernels store every row they load
-            p->max_chunks = ((uint32_t)((halo_bytes + (uint64_t)p->tw * q.step + 15) / 16) + 1 + 255u) & ~255u;
+            // rounded up to whole rows of one chunk per thread: the baked kernels store every row they load
+            p->max_chunks = ((uint32_t)((halo_bytes + (uint64_t)p->tw * q.step + 15) / 16) + 1 + p->nth - 1u) / p->nth * p->nth;
             p->k16 = false;
             p->wide = false;
             p->lds_bytes = wave_fast_lds_bytes(p->max_chunks, (uint32_t)pick, q.lag,
-                                               (p->flags & GAMS_WAVE_DENSE) != 0 || p->serial);
+                                               (p->flags & GAMS_WAVE_DENSE) != 0 || p->serial, p->nth);
             // a launch of at least a round and a half of workgroups ends in smaller tiles, unless the host
             // keeps passes in flight (their tails overlap anyway, and the small tiles cost 3-4 % more work)
             const uint32_t slots = 8u * (uint32_t)std::max(h->cus, 1);
@@ -539,14 +554,14 @@ int wave_launch(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a, hipStream
     return GAMS_OK;
 }
 
-template <int W, int SIZE, int STEP, int LAG, bool NT>
+template <int W, int SIZE, int STEP, int LAG, bool NT, int NTH = 256>
 int wave_launch_fast_nt(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a, hipStream_t st) {
-    auto kern = wave_fast_kernel<W, SIZE, STEP, LAG, NT>;
+    auto kern = wave_fast_kernel<W, SIZE, STEP, LAG, NT, NTH>;
     if (!p->attr_set) {
         GAMS_HIP(h, gams_lds_attr(h, reinterpret_cast<const void *>(kern), p->lds_bytes));
         p->attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)p->tiles.size()), dim3(256), p->lds_bytes, st, a.tiles, a.seq, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)p->tiles.size()), dim3(NTH), p->lds_bytes, st, a.tiles, a.seq, a);
     GAMS_HIP(h, hipGetLastError());
     return GAMS_OK;
 }
@@ -554,10 +569,10 @@ int wave_launch_fast_nt(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a, h
 // sequence loads with the streaming hint once the batch is too large to live in L2 between passes
 // (kStreamBytes: twice the 32 MiB of L2)
 constexpr uint64_t kStreamBytes = 64ull << 20;
-template <int W, int SIZE, int STEP, int LAG>
+template <int W, int SIZE, int STEP, int LAG, int NTH = 256>
 int wave_launch_fast(gams_gpu_t *h, gams_wave_plan_t *p, const WaveArgs &a, hipStream_t st) {
-    return p->set->bytes > kStreamBytes ? wave_launch_fast_nt<W, SIZE, STEP, LAG, true>(h, p, a, st)
-                                        : wave_launch_fast_nt<W, SIZE, STEP, LAG, false>(h, p, a, st);
+    return p->set->bytes > kStreamBytes ? wave_launch_fast_nt<W, SIZE, STEP, LAG, true, NTH>(h, p, a, st)
+                                        : wave_launch_fast_nt<W, SIZE, STEP, LAG, false, NTH>(h, p, a, st);
 }
 
 template <bool NT>
@@ -741,6 +756,14 @@ int gams_wave_plan_set_tile(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tile_wi
     // the LDS), which need the dense rows
     if (rc == GAMS_OK) rc = wave_alloc_ways(h, p);
     return rc;
+}
+
+int gams_wave_plan_set_threads(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t threads) {
+    if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_plan_set_threads: null argument");
+    if (threads != 0 && threads != 64 && threads != 128 && threads != 256)
+        return gams_fail(h, GAMS_EINVAL, "wave_plan_set_threads: 0 (the library's choice), 64, 128 or 256");
+    p->nth_req = threads == 256 ? 0xFFFFFFFFu : threads;
+    return gams_wave_plan_set_tile(h, p, p->tw_req);
 }
 
 int gams_wave_plan_set_guard(gams_gpu_t *h, gams_wave_plan_t *p, float safety, int all_exact) {
@@ -947,12 +970,18 @@ static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
         case 1220: GAMS_RL(12, 20); break;
         case 2001: GAMS_RL(20, 1); break;
         case 2005: GAMS_RL(20, 5); break;
-        case 2801: GAMS_RL(28, 1); break;
+        case 2801:
+            rc = p->nth == 64    ? wave_launch_fast<28, 100, 1, 0, 64>(h, p, a, st)
+                 : p->nth == 128 ? wave_launch_fast<28, 100, 1, 0, 128>(h, p, a, st)
+                                 : wave_launch_fast<28, 100, 1, 0>(h, p, a, st);
+            break;
         default: rc = gams_fail(h, GAMS_ESTATE, "wave: no kernel for this tile size / step"); break;
         }
 #undef GAMS_RL
     } else if (p->fast_w == 28)
-        rc = wave_launch_fast<28, 100, 1, 100>(h, p, a, st);   // baked only (wave_build_geometry)
+        rc = p->nth == 64    ? wave_launch_fast<28, 100, 1, 100, 64>(h, p, a, st)   // baked only (wave_build_geometry)
+             : p->nth == 128 ? wave_launch_fast<28, 100, 1, 100, 128>(h, p, a, st)
+                             : wave_launch_fast<28, 100, 1, 100>(h, p, a, st);
     else if (p->fast_w == 20)
         rc = baked ? wave_launch_fast<20, 100, 1, 100>(h, p, a, st) : wave_launch_fast<20, 0, 0, 0>(h, p, a, st);
     else if (p->taper)
@@ -1256,7 +1285,8 @@ int gams_wave_plan_kernel_name(gams_gpu_t *h, gams_wave_plan_t *p, char *buf, si
         name = std::string("wave_fast_taper_kernel<100, 10, 100, ") + nt + ">";
     else if (p->fast_w) {
         const std::string prm = baked ? "100, " + std::to_string(q.step) + (kind == 1 ? ", 100, " : ", 0, ") : "0, 0, 0, ";
-        name = "wave_fast_kernel<" + std::to_string(p->fast_w) + ", " + prm + nt + ">";
+        name = "wave_fast_kernel<" + std::to_string(p->fast_w) + ", " + prm + nt +
+               (p->nth != 256 ? ", " + std::to_string(p->nth) : std::string()) + ">";
     } else
         name = std::string("wave_tile_kernel<") + (p->k16 ? "unsigned short, " : "unsigned char, ") + (p->wide ? "true>" : "false>");
     std::snprintf(buf, n, "%s", name.c_str());

@@ -474,7 +474,7 @@ __device__ __forceinline__ void z_decide(float nf, float kkf, float S1f, float S
 // Interleaved A/B (tools/ab.py) on 384 Mb: W = 12 runs 115 -> 105 us with the cap.
 // SIZE/STEP/LAG != 0 bake the parameters into the instruction stream (constant bit-field offsets in phase 2);
 // LAG == 0 with SIZE/STEP != 0: the lag stays an argument; all 0 = taken from the arguments at run time.
-template <int W, int SIZE, int STEP, int LAG, bool NT>
+template <int W, int SIZE, int STEP, int LAG, bool NT, int NTH = 256>
 // `tiles` and `seq` are kernel parameters of their own, in front of the argument block: with
 // -mllvm -amdgpu-kernarg-preload-count the command processor delivers the first kernel-argument
 // dwords in SGPRs at wave start, so the tile descriptor's load does not wait for a scalar load of
@@ -482,12 +482,17 @@ template <int W, int SIZE, int STEP, int LAG, bool NT>
 __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t *const seq_p, const WaveArgs &a) {
     static_assert(W % 4 == 0 && W <= 28 && (((W / 4) & 1) == 1 || W == 8), "W/4 odd (LDS bank stride), or W = 8 (64-bit reads); one mask bit per window");
     static_assert((SIZE == 0) == (STEP == 0) && (LAG == 0 || STEP != 0), "bake size and step together; lag only with them");
+    // NTH threads per workgroup.  256 everywhere except the step-1 kernels, which may run a tile per one or two
+    // waves (NTH = 64 / 128, W > 12, baked): every barrier of the tile then waits for fewer waves (see
+    // profiles/r03_barrier_skew.txt: the four waves of a workgroup reach a barrier 3,000-4,500 cycles apart).
+    static_assert(NTH == 256 || ((NTH == 64 || NTH == 128) && STEP != 0 && W > 12), "narrow workgroups: baked kernels with W > 12");
+    constexpr uint32_t NT_ = (uint32_t)NTH;
     // Windows per tile.  Baked parameters: 256*W - LAG - 1, so that the tile's K slots (its windows
     // plus the lag+1 in front) are exactly 256*W: every thread of phase 2 owns W slots, which are
     // also the block of outgoing counts of the phase-3 thread with the same index.
     // (SIZE and STEP baked, LAG == 0: the lag is an argument -- `gams wave --lag N` keeps the baked kernel; the
     // reference's own benchmark runs 100 / 5 / 200 and 100 / 20 / 50, doc/benchmark/Atha.md:55,276-280)
-    const uint32_t TW = STEP != 0 ? 256u * W - (LAG ? (uint32_t)LAG : a.lag) - 1u : 256u * W;
+    const uint32_t TW = STEP != 0 ? NT_ * W - (LAG ? (uint32_t)LAG : a.lag) - 1u : NT_ * W;
     constexpr int WD = W / 4;
     extern __shared__ __align__(16) unsigned char smem[];
     // LDS carve: BM (1 bit per base, 16 per chunk) | scratch (16 words) | K | PS | SG (dense only)
@@ -497,9 +502,9 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
     uint8_t *K = reinterpret_cast<uint8_t *>(scr + 16);
     const uint32_t *KW = reinterpret_cast<const uint32_t *>(K);
     // PS[t] = (sum k, sum k^2) over K slots [t*W, t*W + W)   (baked kernels; 256 + 16 entries)
-    uint2 *PS = reinterpret_cast<uint2 *>(K + ((256u * W + (LAG ? (uint32_t)LAG : a.lag) + 1u + 31u) & ~15u));
-    uint16_t *RK = reinterpret_cast<uint16_t *>(PS + 272);   // phase 4b (W > 12): a thread's rank inside its wave
-    uint8_t *SG = reinterpret_cast<uint8_t *>(RK + 256);
+    uint2 *PS = reinterpret_cast<uint2 *>(K + ((NT_ * W + (LAG ? (uint32_t)LAG : a.lag) + 1u + 31u) & ~15u));
+    uint16_t *RK = reinterpret_cast<uint16_t *>(PS + NT_ + 16u);   // phase 4b (W > 12): a thread's rank inside its wave
+    uint8_t *SG = reinterpret_cast<uint8_t *>(RK + NT_);
 
     const uint32_t tid = threadIdx.x;
     if (a.stamps != nullptr && threadIdx.x == 0)
@@ -524,8 +529,8 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
         // Baked parameters: the tile never has more than NCH chunks, so every thread issues
         // all of its NLD loads back to back with no bounds logic (the bytes past the tile
         // are the next tile's or the seqset's tail slack), classifies, and stores.
-        constexpr uint32_t NCH = (256u * W * STEP + SIZE + 30u) / 16u + 1u;   // TW + lag + 1 = 256 * W windows' worth
-        constexpr uint32_t NLD = (NCH + 255u) / 256u;
+        constexpr uint32_t NCH = (NT_ * W * STEP + SIZE + 30u) / 16u + 1u;   // TW + lag + 1 = 256 * W windows' worth
+        constexpr uint32_t NLD = (NCH + NT_ - 1u) / NT_;
         uint4 v[NLD];
         // The tile's first row holds the halo (the previous tile's last 1.1 KB) and its last row the bytes
         // the next tile will want as ITS halo: those two rows are read with plain loads -- the last one leaves
@@ -534,14 +539,14 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
         // (gpurun_out/r2_ab12.log); the two-round 120-Mb launch does not care (27.2-27.4 us).
         v[0] = load_stream16<false>(src + tid);
 #pragma unroll
-        for (uint32_t k = 1; k + 1u < NLD; ++k) v[k] = load_stream16<NT>(src + tid + 256u * k);
+        for (uint32_t k = 1; k + 1u < NLD; ++k) v[k] = load_stream16<NT>(src + tid + NT_ * k);
         // the last row is only partly inside the largest tile: lanes past it re-read the tile's last
         // chunk (one more request for the same line; their masks land behind the tile's last chunk in
         // BM, where nothing reads).  Unconditional: a predicated load sits in its own basic block and
         // makes hipcc wait vmcnt(0) right behind it -- which the tapered kernel's inlined bodies did.
-        v[NLD - 1u] = load_stream16<false>(src + min(tid + 256u * (NLD - 1u), NCH - 1u));
+        v[NLD - 1u] = load_stream16<false>(src + min(tid + NT_ * (NLD - 1u), NCH - 1u));
 #pragma unroll
-        for (uint32_t k = 0; k < NLD; ++k) BM[tid + 256u * k] = (uint16_t)gc_mask16(v[k]);
+        for (uint32_t k = 0; k < NLD; ++k) BM[tid + NT_ * k] = (uint16_t)gc_mask16(v[k]);
     } else
     // Two batches of four 16-B loads stay in flight per thread: the next batch is issued
     // before the current one is classified.  Loads and LDS stores are unconditional (index
@@ -579,9 +584,9 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
         // offset: ~6 VALU per window, no LDS access inside the run, counts stored 4 per dword.
         if (vb >= 0) {
             counted = true;
-            constexpr uint32_t NK_MAX = 256u * W;                    // = lag + 1 + TW
+            constexpr uint32_t NK_MAX = NT_ * W;                    // = lag + 1 + TW
             constexpr uint32_t RUN = (uint32_t)W;
-            static_assert(NK_MAX == 256u * RUN, "phase 2: W slots per thread");
+            static_assert(NK_MAX == NT_ * RUN, "phase 2: W slots per thread");
             constexpr uint32_t NBITS = RUN * (uint32_t)STEP + (uint32_t)SIZE;
             constexpr uint32_t NDW = (NBITS + 31u) / 32u + 1u;           // + 1 for the realignment
             const uint32_t nK = lag + 1u + nvalid;
@@ -627,7 +632,7 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
     }
     if (!counted) {
         const uint32_t nK = lag + 1u + nvalid;
-        const uint32_t run = (nK + 255u) >> 8;
+        const uint32_t run = (nK + NT_ - 1u) / NT_;
         uint32_t idx = tid * run;
         const uint32_t iend = min(idx + run, nK);
         for (; idx < iend && vb + (int32_t)idx < 0; ++idx) K[idx] = 0;   // before the ctg start
@@ -731,7 +736,7 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
                     // of the tile never reaches past block 255 (t + lag / W <= 255); threads behind the tile's
                     // last window are masked off and stop at the array's end.
                     const uint32_t full = lag / (uint32_t)W, rem = lag % (uint32_t)W;
-                    const uint32_t trips = min(full, 272u - tid);     // (masked threads: stay inside PS)
+                    const uint32_t trips = min(full, NT_ + 16u - tid);     // (masked threads: stay inside PS)
 #pragma unroll 4
                     for (uint32_t j = 0; j < trips; ++j) {
                         const uint2 ps = PS[tid + j];
@@ -902,7 +907,7 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
         const uint32_t head = min((uint32_t)(0u - (uint32_t)g0) & 3u, nvalid);
         const uint32_t ngrp = (nvalid - head) >> 2;
         const uint32_t *SW = reinterpret_cast<const uint32_t *>(SG);
-        for (uint32_t j = tid; j < ngrp; j += 256u) {
+        for (uint32_t j = tid; j < ngrp; j += NT_) {
             const uint32_t idx = head + 4u * j;
             const uint32_t ka = idx + lag + 1u;
             const uint32_t kc = __builtin_amdgcn_alignbyte(KW[(ka >> 2) + 1u], KW[ka >> 2], ka & 3u);
@@ -912,11 +917,12 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
             *reinterpret_cast<uint32_t *>(a.dense_sig + g0 + idx) = sc;
         }
         const uint32_t tail0 = head + 4u * ngrp;
+        constexpr uint32_t TL = NTH > 64 ? 64u : 8u;               // first lane of the tail rows: another wave than the head's, if there is one
         if (tid < head) {
             a.dense_cnt[g0 + tid] = K[tid + lag + 1u];
             a.dense_sig[g0 + tid] = (int8_t)SG[tid];
-        } else if (tid >= 64u && tail0 + (tid - 64u) < nvalid) {   // (another wave than the head's)
-            const uint32_t idx = tail0 + (tid - 64u);
+        } else if (tid >= TL && tail0 + (tid - TL) < nvalid) {
+            const uint32_t idx = tail0 + (tid - TL);
             a.dense_cnt[g0 + idx] = K[idx + lag + 1u];
             a.dense_sig[g0 + idx] = (int8_t)SG[idx];
         }
@@ -965,13 +971,15 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
             uint2 *const MB = PS;
             MB[tid] = make_uint2(both, crest);
             RK[tid] = (uint16_t)(inc - mine);              // < 64 * W
-            const uint32_t c1 = scr[0], c2 = c1 + scr[1], c3 = c2 + scr[2], tot = c3 + scr[3];
+            const uint32_t c1 = scr[0], c2 = NTH > 64 ? c1 + scr[1] : c1, c3 = NTH > 128 ? c2 + scr[2] : c2,
+                           tot = NTH > 128 ? c3 + scr[3] : c3;   // (one or two waves: the missing wave totals count as empty)
             __syncthreads();
             if (tid == 0) a.tile_cnt[blockIdx.x] = tot;
             const uint32_t lim = min(tot, a.tile_cap);
-            for (uint32_t r = tid; r < lim; r += 256u) {
-                const uint32_t wr = (r >= c1 ? 1u : 0u) + (r >= c2 ? 1u : 0u) + (r >= c3 ? 1u : 0u);
-                const uint32_t rl = r - (r >= c3 ? c3 : r >= c2 ? c2 : r >= c1 ? c1 : 0u);
+            for (uint32_t r = tid; r < lim; r += NT_) {
+                const uint32_t wr = NTH == 64 ? 0u : NTH == 128 ? (r >= c1 ? 1u : 0u)
+                                                          : (r >= c1 ? 1u : 0u) + (r >= c2 ? 1u : 0u) + (r >= c3 ? 1u : 0u);
+                const uint32_t rl = r - (wr == 3u ? c3 : wr == 2u ? c2 : wr == 1u ? c1 : 0u);
                 // the last thread of wave wr whose rank is <= rl (ranks do not decrease; a thread without
                 // peaks shares its rank with its successor, so the last one is the owner)
                 uint32_t t = wr * 64u;
@@ -1000,11 +1008,11 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
     wave_stamp(a, 6);
 }
 
-template <int W, int SIZE, int STEP, int LAG, bool NT>
-__global__ __launch_bounds__(256, 8) void wave_fast_kernel(const WaveTile *const tiles_p, const uint8_t *const seq_p,
+template <int W, int SIZE, int STEP, int LAG, bool NT, int NTH = 256>
+__global__ __launch_bounds__(NTH, 8) void wave_fast_kernel(const WaveTile *const tiles_p, const uint8_t *const seq_p,
                                                            const WaveArgs a) {
     const WaveTile tl = tiles_p[blockIdx.x];         // issued before anything waits for the argument block
-    wave_fast_tile<W, SIZE, STEP, LAG, NT>(tl, seq_p, a);
+    wave_fast_tile<W, SIZE, STEP, LAG, NT, NTH>(tl, seq_p, a);
 }
 
 // Tapered launch (baked parameters): the tile table ends in tiles of 8 and then 4 windows per thread

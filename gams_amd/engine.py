@@ -136,6 +136,10 @@ class WavePlan:
         """windows per workgroup (0: the library's choice); 1024 / 2048 / 3072 / 5120 / 7168 select the fast kernels' W"""
         self.eng.check(self.eng.lib.gams_wave_plan_set_tile(self.eng.h, self.p, tile_windows))
 
+    def set_threads(self, threads):
+        """threads per workgroup of the step-1 W = 28 kernels: 64 / 128 / 256 (0: the library's choice)"""
+        self.eng.check(self.eng.lib.gams_wave_plan_set_threads(self.eng.h, self.p, threads))
+
     def set_lane(self, lane):
         """run this plan on HIP stream `lane` (+ way) of the handle: plans on different lanes overlap"""
         self.eng.check(self.eng.lib.gams_wave_plan_set_lane(self.eng.h, self.p, lane))

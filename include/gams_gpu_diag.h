@@ -46,6 +46,10 @@ int gams_wave_plan_kernel_name(gams_gpu_t *h, gams_wave_plan_t *plan, char *buf,
 /* Tuning/diagnostics: windows per tile (0 = library default), and how many
  * windows of the last run took the exact-order f32 re-evaluation. */
 int gams_wave_plan_set_tile(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tile_windows);
+/* Threads per workgroup of the step-1 tile kernels (size 100, step 1, W = 28): 64, 128 or 256, 0 = the library's
+ * choice.  A tile is then 64 / 128 / 256 threads x 28 windows; other plans ignore the request.  Rebuilds the tiling
+ * like gams_wave_plan_set_tile. */
+int gams_wave_plan_set_threads(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t threads);
 int gams_wave_exact_count(gams_gpu_t *h, gams_wave_plan_t *p, uint64_t *n_exact);
 /* Diagnostics of the integer decision's guard band (stat.rs:36-38 is an f32 comparison; windows
  * whose integer margin is inside the band are re-evaluated in the reference's exact f32 order).

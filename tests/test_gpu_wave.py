@@ -616,6 +616,8 @@ def test_plan_kernel_name_follows_the_plan(eng):
             for tw in (5120, 7168):
                 plan.set_tile(tw)
                 names[f"step 1, {tw}"] = plan.kernel_name()
+            plan.set_threads(256)
+            names["step 1, 7168, four waves"] = plan.kernel_name()
         plan.close()
     ss.close()
     # a 300-kb ctg is a handful of tiles: the smallest tile, which is baked for the headline parameters only
@@ -623,7 +625,8 @@ def test_plan_kernel_name_follows_the_plan(eng):
     assert names["headline, 3072"] == "wave_fast_kernel<12, 100, 10, 100, false>"
     assert names[(100, 1, 100, 1.0)] == "wave_fast_kernel<4, 0, 0, 0, false>"
     assert names["step 1, 5120"] == "wave_fast_kernel<20, 100, 1, 100, false>"
-    assert names["step 1, 7168"] == "wave_fast_kernel<28, 100, 1, 100, false>"
+    assert names["step 1, 7168"] == "wave_fast_kernel<28, 100, 1, 100, false, 64>"       # W = 28: a tile per wave
+    assert names["step 1, 7168, four waves"] == "wave_fast_kernel<28, 100, 1, 100, false>"
     assert names[(50, 7, 33, 1.0)] == "wave_fast_kernel<4, 0, 0, 0, false>"
     assert names[(100, 10, 100, 0.5)] == "jac_eval_kernel"
     assert names[(100, 1000, 100, 1.0)].startswith("wave_direct_count_kernel")
@@ -667,6 +670,37 @@ def test_size_and_step_baked_lag_as_argument(eng, s288c, step):
                 plan.close()
             ss.close()
     assert any(f", 100, {step}, 0, " in k for k in seen), seen     # the lag-as-argument instantiations did run
+
+
+@pytest.mark.parametrize("threads", [64, 128, 256])
+def test_step1_tiles_of_one_two_or_four_waves(eng, s288c, threads):
+    """The step-1 W = 28 kernels run a tile per 64, 128 or 256 threads (gams_wave_plan_set_threads): counts, signals and
+    peaks against the oracle on ragged ctgs, lag baked (100) and as an argument, at the lags around the narrow tile's
+    layout boundaries (lag + 1 <= threads / 2 * 28, the PS blocks of 28 slots), dense rows and peaks."""
+    pool = [bytes(s288c["I"][:90_000]), synth(41_234, 5).tobytes(), bytes(s288c["Mito"][:9_000]), synth(1_777, 6).tobytes(),
+            synth(1_691 + 99, 7).tobytes(), synth(1_692 + 99, 8).tobytes(), synth(3_475 + 99, 9).tobytes()]
+    half = threads // 2 * 28
+    seen = set()
+    for lag in [100, 2, 27, 28, 29, 55, 56, 57, 99, 101, 200, half - 2, half - 1, half]:
+        seqs = [sq for sq in pool if len(sq) - 99 >= lag]
+        ss = engine.SeqSet(eng, seqs)
+        for thr in (3.0, 1.5) if lag in (100, 56) else (3.0,):
+            plan = engine.WavePlan(eng, ss, 100, 1, lag, thr, 1.0, flags=_lib.WAVE_PEAKS | _lib.WAVE_DENSE, tile_windows=7168)
+            plan.set_threads(threads)
+            seen.add(plan.kernel_name())
+            plan.run()
+            pk = plan.peaks()
+            for c, sq in enumerate(seqs):
+                ocnt, _, osig = ora.wave_windows(sq, 100, 1, lag, thr, 1.0)
+                cnt, sig = plan.dense(c)
+                assert np.array_equal(cnt, ocnt) and np.array_equal(sig.astype(np.int32), osig), (threads, lag, thr, c)
+                mine = pk[pk["ctg"] == c]
+                idx = np.flatnonzero(osig)
+                assert np.array_equal(mine["window"], idx) and np.array_equal(mine["signal"], osig[idx]), (threads, lag, c)
+            plan.close()
+        ss.close()
+    tag = "" if threads == 256 else f", {threads}"
+    assert f"wave_fast_kernel<28, 100, 1, 100, false{tag}>" in seen and f"wave_fast_kernel<28, 100, 1, 0, false{tag}>" in seen, seen
 
 
 def test_plans_sharing_a_kernel_function_keep_their_lds(eng, s288c):

@@ -47,6 +47,13 @@ __global__ __launch_bounds__(256, 8) void k(unsigned *out, unsigned seed, unsign
         if (KIND == 27) { REP64(asm volatile("v_mqsad_pk_u16_u8 %0, %0, %1, %0\n v_mqsad_pk_u16_u8 %2, %2, %3, %2" : "+v"(qa), "+v"(b), "+v"(qc), "+v"(d));) }
         if (KIND == 28) { REP64(asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cmp_gt_f32 s[4:5], %2, %3" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd) : : "vcc", "s4", "s5");) }
         if (KIND == 29) { REP64(asm volatile("v_mul_lo_u32 %0, %0, %1\n v_mul_hi_u32 %2, %2, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }
+        if (KIND == 30) { REP64(asm volatile("v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %2, %2, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "s"(0x01010101u));) }
+        if (KIND == 31) { REP64(asm volatile("v_mul_u32_u24 %0, 0x204081, %0\n v_mul_u32_u24 %2, 0x204081, %2" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }
+        if (KIND == 32) { REP64(asm volatile("v_perm_b32 %0, %0, %0, %4\n v_perm_b32 %2, %2, %2, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "s"(0x03030303u));) }
+        if (KIND == 33) { REP64(asm volatile("v_lshl_add_u32 %0, %0, 8, %0\n v_lshl_add_u32 %2, %2, 16, %2" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }
+        if (KIND == 34) { REP64(asm volatile("v_mul_lo_u32 %0, %0, %1\n v_mul_lo_u32 %2, %2, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }
+        if (KIND == 35) { REP64(asm volatile("v_mul_hi_u32 %0, %0, %1\n v_mul_hi_u32 %2, %2, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }
+        if (KIND == 36) { REP64(asm volatile("v_add3_u32 %0, %0, %1, %4\n v_add3_u32 %2, %2, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "s"(0xfbfcfdffu));) }
         if (KIND == 13) { REP64(asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_or_b32 %2, %2, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "vcc");) }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
@@ -105,5 +112,12 @@ int main() {
     run<27>("v_mqsad_pk_u16_u8", d_out, d_cyc);
     run<28>("v_cmp_f32 (vcc / sgpr)", d_out, d_cyc);
     run<29>("v_mul_lo_u32 + v_mul_hi_u32", d_out, d_cyc);
+    run<30>("v_mul_lo_u32 v, v, s", d_out, d_cyc);
+    run<34>("v_mul_lo_u32 v, v, v", d_out, d_cyc);
+    run<35>("v_mul_hi_u32 v, v, v", d_out, d_cyc);
+    run<31>("v_mul_u32_u24 literal", d_out, d_cyc);
+    run<32>("v_perm_b32 v, v, v, s", d_out, d_cyc);
+    run<33>("v_lshl_add_u32", d_out, d_cyc);
+    run<36>("v_add3_u32 v, v, v, s", d_out, d_cyc);
     return 0;
 }
