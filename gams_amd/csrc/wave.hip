@@ -180,6 +180,7 @@ constexpr uint32_t kCounterRing = 128;       // one counter slot (kShards lines)
 constexpr size_t kSlotWords = (size_t)kShards * kShardWords;
 constexpr uint32_t kMaxTileBytes = 65520;  // chunk prefix is 16 bits
 constexpr uint32_t kMaxTw = 8192;          // 2 bits/iteration in a 64-bit register
+constexpr uint32_t kOffOneGroup = 32768;   // tables up to here: wave_offsets_kernel (one workgroup, one launch)
 
 size_t wave_lds_bytes(uint32_t max_chunks, uint32_t max_win, bool wide, bool k16) {
     size_t b = 0;
@@ -1355,8 +1356,18 @@ int gams_wave_peaks(gams_gpu_t *h, gams_wave_plan_t *p, const gams_peak_t **peak
                                         reinterpret_cast<void **>(&p->d_dense), &p->d_dense_bytes));
             p->dense_cap = p->d_dense_bytes / sizeof(gams_peak_t);
         }
-        hipLaunchKernelGGL(wave_offsets_kernel, dim3(1), dim3(1024), 0, h->readback, w.d_tile_cnt, (uint32_t)nt,
-                           p->d_tile_off, d_totals);
+        if (nt <= kOffOneGroup) {
+            hipLaunchKernelGGL(wave_offsets_kernel, dim3(1), dim3(1024), 0, h->readback, w.d_tile_cnt, (uint32_t)nt,
+                               p->d_tile_off, d_totals);
+        } else {
+            const unsigned spans = (unsigned)((nt + kOffSpan - 1) / kOffSpan);
+            hipLaunchKernelGGL(wave_offsets_sum_kernel, dim3(spans), dim3(1024), 0, h->readback, w.d_tile_cnt, (uint32_t)nt,
+                               p->d_tile_off);
+            hipLaunchKernelGGL(wave_offsets_base_kernel, dim3(1), dim3(1024), 0, h->readback, (uint32_t)nt, p->d_tile_off,
+                               d_totals);
+            hipLaunchKernelGGL(wave_offsets_scan_kernel, dim3(spans), dim3(1024), 0, h->readback, w.d_tile_cnt, (uint32_t)nt,
+                               p->d_tile_off);
+        }
         GAMS_HIP(h, hipGetLastError());
         hipLaunchKernelGGL(wave_gather_kernel, dim3((unsigned)nt), dim3(64), 0, h->readback, w.d_peaks,
                            p->tile_cap, w.d_tile_cnt, p->d_tile_off, p->d_dense, (unsigned long long)p->dense_cap);
@@ -1560,13 +1571,26 @@ int rows_emit(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t wi, hipStream_t st, u
     uint32_t nb = t.nb_cap;
     unsigned long long *blk_off = t.blk_off, *blk_tot = t.blk_off + nb;
     void *args_off2[] = {&blk_len, &nb, &blk_off, &blk_tot};
-    kernel(reinterpret_cast<const void *>(wave_offsets_kernel), 1, 1024, args_off1);
+    // (exclusive prefix of n counts: one workgroup, or spans of kOffSpan counts in three launches -- wave_kernels.hpp)
+    auto offsets = [&](void **all4, void **cnt_n_off, void **n_off_tot, uint32_t n) {
+        if (n <= kOffOneGroup) {
+            kernel(reinterpret_cast<const void *>(wave_offsets_kernel), 1, 1024, all4);
+            return;
+        }
+        const unsigned spans = (n + kOffSpan - 1u) / kOffSpan;
+        kernel(reinterpret_cast<const void *>(wave_offsets_sum_kernel), spans, 1024, cnt_n_off);
+        kernel(reinterpret_cast<const void *>(wave_offsets_base_kernel), 1, 1024, n_off_tot);
+        kernel(reinterpret_cast<const void *>(wave_offsets_scan_kernel), spans, 1024, cnt_n_off);
+    };
+    void *args_off1a[] = {&tile_cnt, &nt32, &tile_off}, *args_off1b[] = {&nt32, &tile_off, &d_totals};
+    offsets(args_off1, args_off1a, args_off1b, nt32);
     kernel(reinterpret_cast<const void *>(wave_gather_kernel), (unsigned)nt, 64, args_gather);
     kernel(reinterpret_cast<const void *>(rows_link_kernel), nb, 256, args_rows);
     kernel(reinterpret_cast<const void *>(rows_heads_kernel), 1, 1024, args_rows);
     kernel(reinterpret_cast<const void *>(rows_tail_kernel), (unsigned)((r->cap + 255) / 256), 256, args_rows);
     kernel(reinterpret_cast<const void *>(rows_len_kernel), nb, 256, args_rows);
-    kernel(reinterpret_cast<const void *>(wave_offsets_kernel), 1, 1024, args_off2);
+    void *args_off2a[] = {&blk_len, &nb, &blk_off}, *args_off2b[] = {&nb, &blk_off, &blk_tot};
+    offsets(args_off2, args_off2a, args_off2b, nb);
     kernel(reinterpret_cast<const void *>(rows_write_kernel), nb, 256, args_rows);
     // the words (sizes, totals, per-ctg offsets: one block) and -- sized by the previous pass -- the text itself go to the
     // host behind the kernels

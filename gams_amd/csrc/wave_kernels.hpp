@@ -1290,6 +1290,106 @@ __global__ __launch_bounds__(1024) void wave_offsets_kernel(const uint32_t *tile
     }
 }
 
+// The same for tables too long for one workgroup (a tile per wave at step 1: 1.8 million tiles for a human genome, where
+// the kernel above -- every lane walking its own 1,800 counts, a cache line apart from its neighbour's -- took 5.8 ms,
+// more than twice the pass itself): spans of kOffSpan counts, three launches.  (1) a workgroup per span: its sum and
+// its maximum, packed into the span's first offset word (sum below bit 40, maximum above: a span holds at most
+// 8192 x 65535 records); (2) one workgroup: exclusive prefix over the span words, in place, and the two totals;
+// (3) a workgroup per span: the offsets, from the span's base.  Every load and store is coalesced.
+constexpr uint32_t kOffSpan = 8192;
+constexpr unsigned long long kOffSumMask = (1ull << 40) - 1ull;
+
+// exclusive prefix of v over the 1024 threads of the workgroup; total = the sum over all of them
+__device__ __forceinline__ unsigned long long block_excl_scan_1024(unsigned long long v, unsigned long long *wsum,
+                                                                   unsigned long long &total) {
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const unsigned long long inc = wave_incl_scan_u64(v);
+    __syncthreads();                                    // (wsum may still be read from the previous call)
+    if (lane == 63u) wsum[wv] = inc;
+    __syncthreads();
+    unsigned long long base = 0, all = 0;
+    for (uint32_t w = 0; w < 16u; ++w) {
+        const unsigned long long x = wsum[w];
+        if (w < wv) base += x;
+        all += x;
+    }
+    total = all;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(1024) void wave_offsets_sum_kernel(const uint32_t *cnt, uint32_t n, unsigned long long *off) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ uint32_t wmax[16];
+    const uint32_t tid = threadIdx.x, b0 = blockIdx.x * kOffSpan;
+    unsigned long long mine = 0;
+    uint32_t mx = 0;
+    for (uint32_t i = 0; i < kOffSpan / 1024u; ++i) {
+        const uint32_t t = b0 + i * 1024u + tid;
+        const uint32_t c = t < n ? cnt[t] : 0u;
+        mine += c;
+        mx = max(mx, c);
+    }
+    for (int d = 32; d; d >>= 1) {
+        mine += (unsigned long long)__shfl_xor((long long)mine, d, 64);
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    }
+    if ((tid & 63u) == 0u) {
+        wsum[tid >> 6] = mine;
+        wmax[tid >> 6] = mx;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long all = 0;
+        uint32_t worst = 0;
+        for (uint32_t w = 0; w < 16u; ++w) {
+            all += wsum[w];
+            worst = max(worst, wmax[w]);
+        }
+        off[b0] = all | ((unsigned long long)worst << 40);
+    }
+}
+
+__global__ __launch_bounds__(1024) void wave_offsets_base_kernel(uint32_t n, unsigned long long *off,
+                                                                 unsigned long long *totals) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ uint32_t wmax[16];
+    const uint32_t tid = threadIdx.x, nb = (n + kOffSpan - 1u) / kOffSpan;
+    unsigned long long running = 0;
+    uint32_t mx = 0;
+    for (uint32_t c0 = 0; c0 < nb; c0 += 1024u) {
+        const uint32_t b = c0 + tid;
+        const unsigned long long word = b < nb ? off[(size_t)b * kOffSpan] : 0ull;
+        mx = max(mx, (uint32_t)(word >> 40));
+        unsigned long long tot;
+        const unsigned long long ex = block_excl_scan_1024(word & kOffSumMask, wsum, tot);
+        if (b < nb) off[(size_t)b * kOffSpan] = running + ex;
+        running += tot;
+    }
+    for (int d = 32; d; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    if ((tid & 63u) == 0u) wmax[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t worst = 0;
+        for (uint32_t w = 0; w < 16u; ++w) worst = max(worst, wmax[w]);
+        totals[0] = running;
+        totals[1] = worst;
+    }
+}
+
+__global__ __launch_bounds__(1024) void wave_offsets_scan_kernel(const uint32_t *cnt, uint32_t n, unsigned long long *off) {
+    __shared__ unsigned long long wsum[16];
+    const uint32_t tid = threadIdx.x, b0 = blockIdx.x * kOffSpan;
+    unsigned long long running = off[b0];               // every thread, before anybody overwrites it (the scan's first barrier)
+    for (uint32_t i = 0; i < kOffSpan / 1024u; ++i) {
+        const uint32_t t = b0 + i * 1024u + tid;
+        const uint32_t c = t < n ? cnt[t] : 0u;
+        unsigned long long tot;
+        const unsigned long long ex = block_excl_scan_1024(c, wsum, tot);
+        if (t < n) off[t] = running + ex;
+        running += tot;
+    }
+}
+
 // Pack the per-tile slots into one dense, (ctg, window)-ordered array: one wave per tile.  A tile
 // that would not fit `cap` records (or overflowed its slot) is skipped: the host regrows and repeats.
 __global__ __launch_bounds__(64) void wave_gather_kernel(const gams_peak_t *slots, uint32_t tile_cap,

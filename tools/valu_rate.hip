@@ -54,6 +54,13 @@ __global__ __launch_bounds__(256, 8) void k(unsigned *out, unsigned seed, unsign
         if (KIND == 34) { REP64(asm volatile("v_mul_lo_u32 %0, %0, %1\n v_mul_lo_u32 %2, %2, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }
         if (KIND == 35) { REP64(asm volatile("v_mul_hi_u32 %0, %0, %1\n v_mul_hi_u32 %2, %2, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }
         if (KIND == 36) { REP64(asm volatile("v_add3_u32 %0, %0, %1, %4\n v_add3_u32 %2, %2, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "s"(0xfbfcfdffu));) }
+        if (KIND == 40) { REP64(asm volatile("v_mul_lo_u32 %0, %1, %3\n v_mul_lo_u32 %2, %3, %1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }
+        if (KIND == 41) { REP64(asm volatile("v_mul_u32_u24 %0, %1, %3\n v_mul_u32_u24 %2, %3, %1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }
+        if (KIND == 42) { REP64(asm volatile("v_perm_b32 %0, %1, %3, %4\n v_perm_b32 %2, %3, %1, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "s"(0x03030303u));) }
+        if (KIND == 43) { REP64(asm volatile("v_dot4_u32_u8 %0, %1, %3, %0\n v_dot4_u32_u8 %2, %3, %1, %2" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }
+        if (KIND == 44) { REP64(asm volatile("v_mad_u32_u24 %0, %1, %3, %0\n v_mad_u32_u24 %2, %3, %1, %2" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }
+        if (KIND == 45) { REP64(asm volatile("v_add3_u32 %0, %1, %3, %0\n v_add3_u32 %2, %3, %1, %2" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }
+        if (KIND == 46) { REP64(asm volatile("v_bfe_u32 %0, %1, 7, 4\n v_bfe_u32 %2, %3, 11, 4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }
         if (KIND == 13) { REP64(asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_or_b32 %2, %2, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "vcc");) }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
@@ -119,5 +126,12 @@ int main() {
     run<32>("v_perm_b32 v, v, v, s", d_out, d_cyc);
     run<33>("v_lshl_add_u32", d_out, d_cyc);
     run<36>("v_add3_u32 v, v, v, s", d_out, d_cyc);
+    run<40>("v_mul_lo_u32 d, b, c (live operands)", d_out, d_cyc);
+    run<41>("v_mul_u32_u24 d, b, c (live)", d_out, d_cyc);
+    run<42>("v_perm_b32 d, b, c, s (live)", d_out, d_cyc);
+    run<43>("v_dot4_u32_u8 d, b, c, d (live)", d_out, d_cyc);
+    run<44>("v_mad_u32_u24 d, b, c, d (live)", d_out, d_cyc);
+    run<45>("v_add3_u32 d, b, c, d (live)", d_out, d_cyc);
+    run<46>("v_bfe_u32 d, b, 7, 4", d_out, d_cyc);
     return 0;
 }
