@@ -170,13 +170,14 @@ __device__ __forceinline__ uint64_t wave_incl_scan(uint64_t x) { return wave_inc
 
 // Exclusive scan over a 256-thread workgroup (4 waves).  `ws` is LDS scratch of
 // 4 elements; the call contains two barriers and may be used back to back.
-template <typename T>
+template <typename T, int NTH = 256>
 __device__ __forceinline__ T block_excl_scan_256(T v, T *ws, T &total) {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     T inc = wave_incl_scan(v);
     if (lane == 63) ws[wv] = inc;
     __syncthreads();
-    T w0 = ws[0], w1 = ws[1], w2 = ws[2], w3 = ws[3];
+    // (NTH = 64 / 128: workgroups of one or two waves, the missing waves count as empty)
+    T w0 = ws[0], w1 = NTH > 64 ? ws[1] : (T)0, w2 = NTH > 128 ? ws[2] : (T)0, w3 = NTH > 128 ? ws[3] : (T)0;
     __syncthreads();
     T base = (wv > 0 ? w0 : (T)0) + (wv > 1 ? w1 : (T)0) + (wv > 2 ? w2 : (T)0);
     total = w0 + w1 + w2 + w3;

@@ -360,6 +360,9 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
                 const uint32_t want = p->nth_req == 0 ? 64u : p->nth_req;       // the library's choice: one wave per tile
                 if ((want == 64 || want == 128) && q.lag + 1u <= (want / 2u) * 28u) p->nth = want;
             }
+            // (diagnostics: the headline kernel in workgroups of one or two waves, on request only -- see DESIGN 3.1)
+            if (pick == 12 && q.size == 100 && q.step == 10 && q.lag == 100 && (p->nth_req == 64 || p->nth_req == 128))
+                p->nth = p->nth_req;
             // baked kernels: the tile's windows plus the lag+1 in front fill nth*W slots exactly
             p->tw = wave_is_baked(q, pick) ? p->nth * pick - q.lag - 1u : 256u * pick;
             p->max_win = p->tw + q.lag + 1;
@@ -375,7 +378,7 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
             const bool headline = q.size == 100 && q.step == 10 && q.lag == 100;
             const bool want = p->taper_req < 0 ? p->depth == 1 : p->taper_req != 0;
             // (not for influence != 1: the dense rows are compacted by wave_compact_kernel, which knows one tile size)
-            p->taper = want && !p->serial && tw_req == 0 && pick == 12 && headline &&
+            p->taper = want && !p->serial && tw_req == 0 && pick == 12 && headline && p->nth == 256 &&
                        p->total_windows / p->tw >= slots + slots / 2;
             if (p->taper)
                 wave_fill_tiles_tapered(p, slots);
@@ -990,6 +993,8 @@ static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
     else if (p->fast_w == 12)
         rc = !baked ? wave_launch_fast<12, 0, 0, 0>(h, p, a, st)
              : step1 ? wave_launch_fast<12, 100, 1, 100>(h, p, a, st)
+             : p->nth == 64 ? wave_launch_fast<12, 100, 10, 100, 64>(h, p, a, st)
+             : p->nth == 128 ? wave_launch_fast<12, 100, 10, 100, 128>(h, p, a, st)
                      : wave_launch_fast<12, 100, 10, 100>(h, p, a, st);
     else if (p->fast_w == 8)
         rc = baked ? wave_launch_fast<8, 100, 10, 100>(h, p, a, st) : wave_launch_fast<8, 0, 0, 0>(h, p, a, st);

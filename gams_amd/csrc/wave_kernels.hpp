@@ -485,7 +485,7 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
     // NTH threads per workgroup.  256 everywhere except the step-1 kernels, which may run a tile per one or two
     // waves (NTH = 64 / 128, W > 12, baked): every barrier of the tile then waits for fewer waves (see
     // profiles/r03_barrier_skew.txt: the four waves of a workgroup reach a barrier 3,000-4,500 cycles apart).
-    static_assert(NTH == 256 || ((NTH == 64 || NTH == 128) && STEP != 0 && W > 12), "narrow workgroups: baked kernels with W > 12");
+    static_assert(NTH == 256 || ((NTH == 64 || NTH == 128) && STEP != 0), "narrow workgroups: baked kernels");
     constexpr uint32_t NT_ = (uint32_t)NTH;
     // Windows per tile.  Baked parameters: 256*W - LAG - 1, so that the tile's K slots (its windows
     // plus the lag+1 in front) are exactly 256*W: every thread of phase 2 owns W slots, which are
@@ -944,7 +944,7 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
         gams_peak_t *const region = a.peaks + (size_t)blockIdx.x * a.tile_cap;
         if constexpr (W <= 12) {
             uint32_t tot;
-            const uint32_t ex = block_excl_scan_256<uint32_t>(mine, scr, tot);
+            const uint32_t ex = block_excl_scan_256<uint32_t, NTH>(mine, scr, tot);
             if (tid == 0) a.tile_cnt[blockIdx.x] = tot;
             if (mine) {
                 uint32_t pos = ex;

@@ -703,6 +703,28 @@ def test_step1_tiles_of_one_two_or_four_waves(eng, s288c, threads):
     assert f"wave_fast_kernel<28, 100, 1, 100, false{tag}>" in seen and f"wave_fast_kernel<28, 100, 1, 0, false{tag}>" in seen, seen
 
 
+@pytest.mark.parametrize("threads", [64, 128])
+def test_headline_kernel_in_narrow_workgroups_on_request(eng, s288c, threads):
+    """The W = 12 headline kernel also compiles for one or two waves per tile (a diagnostic: it is HBM bound and loses
+    3-10 % that way, profiles/r03_barrier_skew.txt): same counts, signals and peaks."""
+    seqs = [bytes(s288c["I"]), synth(33_333, 3).tobytes(), bytes(s288c["Mito"][:20_000]), synth(7_680 + 99, 4).tobytes()]
+    ss = engine.SeqSet(eng, seqs)
+    plan = engine.WavePlan(eng, ss, 100, 10, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS | _lib.WAVE_DENSE, tile_windows=3072)
+    plan.set_threads(threads)
+    assert plan.kernel_name() == f"wave_fast_kernel<12, 100, 10, 100, false, {threads}>"
+    plan.run()
+    pk = plan.peaks()
+    for c, sq in enumerate(seqs):
+        ocnt, _, osig = ora.wave_windows(sq, 100, 10, 100, 3.0, 1.0)
+        cnt, sig = plan.dense(c)
+        assert np.array_equal(cnt, ocnt) and np.array_equal(sig.astype(np.int32), osig), (threads, c)
+        mine = pk[pk["ctg"] == c]
+        idx = np.flatnonzero(osig)
+        assert np.array_equal(mine["window"], idx) and np.array_equal(mine["signal"], osig[idx])
+    plan.close()
+    ss.close()
+
+
 def test_plans_sharing_a_kernel_function_keep_their_lds(eng, s288c):
     """The dynamic-LDS limit is an attribute of the kernel FUNCTION, not of a plan: plan A (lag 250:
     more K slots) launches, then plan B (lag 20, same instantiation <W,100,10,0>), then A again -- A's second
