@@ -615,6 +615,11 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
                     k += __popc(field((uint32_t)SIZE + (j - 1u) * (uint32_t)STEP));
                     k -= __popc(field((j - 1u) * (uint32_t)STEP));
                     if ((j & 3u) == 0u) {
+                        // (The test is not needed for correctness -- K has room for NTH * W slots and nothing reads
+                        // the ones past nK -- but the step-1 kernel is 15 % SLOWER without it, 284 -> 327 us on 384 Mb,
+                        // although it is three instructions per store: the load phase of the OTHER tiles on the CU
+                        // grows from 6,250 to 9,770 cycles, everything else stays; gpurun_out/r3_stamps_ab3.txt.
+                        // Yield points put into the z-score loop instead do nothing, profiles/r03_step1_valu_attempts.txt.)
                         if (idx0 + j - 4u < nK) reinterpret_cast<uint32_t *>(K)[(idx0 + j - 4u) >> 2] = packed;
                         s1 = __builtin_amdgcn_udot4(packed, 0x01010101u, s1, false);
                         s2 = __builtin_amdgcn_udot4(packed, packed, s2, false);
@@ -768,12 +773,17 @@ __device__ __forceinline__ void wave_fast_tile(const WaveTile tl, const uint8_t 
         }
         {
             const uint32_t ib = bw + nfull;
-            uint32_t lo = KW[ib];
+            if constexpr (LAG != 0 && (LAG & 3) == 0) {          // whole dwords (v_alignbyte by 0 is not folded away)
 #pragma unroll
-            for (int d = 0; d <= WD; ++d) {
-                const uint32_t hi = KW[ib + d + 1];
-                in[d] = __builtin_amdgcn_alignbyte(hi, lo, sh);
-                lo = hi;
+                for (int d = 0; d <= WD; ++d) in[d] = KW[ib + d];
+            } else {
+                uint32_t lo = KW[ib];
+#pragma unroll
+                for (int d = 0; d <= WD; ++d) {
+                    const uint32_t hi = KW[ib + d + 1];
+                    in[d] = __builtin_amdgcn_alignbyte(hi, lo, sh);
+                    lo = hi;
+                }
             }
         }
         // windows this thread may decide: inside the tile, i >= lag, signalling enabled
