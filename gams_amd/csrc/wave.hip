@@ -335,7 +335,10 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
             // (round 3: W = 28 tiles of ONE wave -- 64 threads, 1,691 windows at lag 100 -- from 4,096 such tiles on:
             // 384 Mb 325 -> 285 us, 120 Mb 112 -> 100 us, 12 Mb 21.9 (W = 20) -> 21.2 us; gpurun_out/r3_ab_threads*.log)
             const bool s1w28 = step1 || (q.size == 100 && q.step == 1 && wave_baked_kind(q, 28) == 2);
-            if (pick == 0 && w == 28 && s1w28 && p->nth_req == 0 && q.lag + 1u <= 32u * 28u &&
+            // (peaks only: with the dense rows the stores of a whole workgroup's windows are worth more -- 384 Mb --signal
+            // 429 us with four waves per tile, 443 with two, 464 with one; gpurun_out/r3_dense_rate2.txt)
+            const bool narrow_ok = !(p->flags & GAMS_WAVE_DENSE) && !p->serial;
+            if (pick == 0 && w == 28 && s1w28 && p->nth_req == 0 && narrow_ok && q.lag + 1u <= 32u * 28u &&
                 p->total_windows / (64u * 28u) >= 4096)
                 pick = w;
             if (pick == 0 && w == 28 && s1w28 && tiles >= 4096)
@@ -357,7 +360,8 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
             // least half of the tile's slots stay windows
             p->nth = 256;
             if (pick == 28 && q.step == 1 && wave_is_baked(q, pick)) {
-                const uint32_t want = p->nth_req == 0 ? 64u : p->nth_req;       // the library's choice: one wave per tile
+                const bool narrow_ok = !(p->flags & GAMS_WAVE_DENSE) && !p->serial;
+                const uint32_t want = p->nth_req == 0 ? (narrow_ok ? 64u : 256u) : p->nth_req;   // the library's choice
                 if ((want == 64 || want == 128) && q.lag + 1u <= (want / 2u) * 28u) p->nth = want;
             }
             // (diagnostics: the headline kernel in workgroups of one or two waves, on request only -- see DESIGN 3.1)

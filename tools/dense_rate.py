@@ -14,6 +14,8 @@ ss = engine.SeqSet(eng, [c["seq"] for c in big])
 for step in (10, 1):
     for name, flags in (("peaks", _lib.WAVE_PEAKS), ("dense (--signal)", _lib.WAVE_DENSE), ("both", _lib.WAVE_PEAKS | _lib.WAVE_DENSE)):
         plan = engine.WavePlan(eng, ss, 100, step, 100, 3.0, 1.0, flags=flags)
+        if len(sys.argv) > 1:
+            plan.set_threads(int(sys.argv[1]))      # step-1 tiles of 64 / 128 / 256 threads
         plan.run_n(100 if step == 10 else 20)
         eng.sync()
         t = []
