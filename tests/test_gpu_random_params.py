@@ -72,3 +72,41 @@ def test_random_parameters(eng, seed):
     assert got == exp, (size, step, lag, thr, infl)
     plan.close()
     ss.close()
+
+
+# GAMS_FUZZ_NARROW=first:count widens this one (profiles/r03_fuzz_log.txt)
+_NFIRST, _NCOUNT = (int(x) for x in os.environ.get("GAMS_FUZZ_NARROW", "0:12").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_NFIRST, _NFIRST + _NCOUNT))
+def test_random_step1_tiles_per_wave(eng, seed):
+    """size 100 / step 1 in workgroups of one or two waves (what a peaks-only plan over a genome runs by default): random
+    lags up to the narrow tile's limit, thresholds, ragged ctgs with N runs and homopolymers; peaks alone and peaks +
+    dense rows, against the oracle."""
+    rng = np.random.default_rng(77000 + seed)
+    threads = int(rng.choice([64, 64, 128]))
+    lag = int(rng.choice([100, 100, int(rng.integers(2, threads // 2 * 28))]))
+    thr = float(rng.choice([1.0, 2.0, 3.0, 3.0, 3.5]))
+    dense = bool(rng.random() < 0.5)
+    n_ctg = int(rng.integers(1, 6))
+    seqs = [random_seq(rng, int(99 + lag + 5 + rng.integers(0, 30000))) for _ in range(n_ctg)]
+    ss = engine.SeqSet(eng, seqs)
+    plan = engine.WavePlan(eng, ss, 100, 1, lag, thr, 1.0, flags=_lib.WAVE_PEAKS | (_lib.WAVE_DENSE if dense else 0),
+                           tile_windows=7168)
+    plan.set_threads(threads)
+    name = plan.kernel_name()                 # (lag * size beyond 16 bits: the general kernel, no narrow form)
+    assert name.endswith(f", {threads}>") or not name.startswith("wave_fast_kernel<28"), name
+    plan.run()
+    pk = plan.peaks()
+    exp = []
+    for c, s in enumerate(seqs):
+        ocnt, _, osig = ora.wave_windows(s, 100, 1, lag, thr, 1.0)
+        if dense:
+            cnt, sig = plan.dense(c)
+            assert np.array_equal(cnt, ocnt) and np.array_equal(sig.astype(np.int32), osig), (threads, lag, thr, c)
+        idx = np.flatnonzero(osig)
+        exp += [(c, int(i), int(ocnt[i]), int(osig[i])) for i in idx]
+    got = [(int(r["ctg"]), int(r["window"]), int(r["gc_count"]), int(r["signal"])) for r in pk]
+    assert got == exp, (threads, lag, thr)
+    plan.close()
+    ss.close()
