@@ -655,6 +655,22 @@ def main():
                 e["windows_per_s_4_in_flight"] = nw * 1000 / (time.perf_counter() - t0)
             extra[tag] = e
             plan.close()
+            if tag == "synth384" and prm["step"] != 1:
+                # SURVEY 8(d)'s secondary figure, configs[3]'s geometry (size 100 / step 1) on the same resident bytes:
+                # compute bound (1 B per window), a tile per wave
+                p1 = engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS, **dict(prm, step=1))
+                for _ in range(20):
+                    p1.run()
+                eng.sync()
+                eng.timer_start()
+                for _ in range(20):
+                    p1.run()
+                ms1 = eng.timer_stop() / 20
+                extra["synth384_step1"] = {"workload": e["workload"] + ", size 100 step 1", "kernel": p1.kernel_name(),
+                                           "windows_per_launch": int(p1.total_windows), "launch_ms": ms1,
+                                           "windows_per_s": p1.total_windows / (ms1 * 1e-3),
+                                           "bytes_per_window": 1, "peaks": int(p1.peaks_count())}
+                p1.close()
             ss.close()
         out["extra"] = extra
     if rank == 0 and world == 1 and not args.no_secondary:
