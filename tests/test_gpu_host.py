@@ -643,6 +643,34 @@ def test_device_rows_golden_and_against_the_host_merge(eng, s288c):
     ss.close()
 
 
+def test_device_rows_over_tiles_of_one_wave(eng):
+    """Step 1 over an S288c-sized synthetic genome: the plan runs a tile per wave (7,000 tiles) and the rows come from
+    the same packed records -- device text == the host's merge + formatting, packed peaks == the oracle's on the ctgs
+    checked."""
+    from gams_amd import synth
+
+    ctgs = synth.genome_ctgs(synth.S288C_LENGTHS, 500000)
+    ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])
+    plan = engine.WavePlan(eng, ss, 100, 1, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS)
+    assert plan.kernel_name() == "wave_fast_kernel<28, 100, 1, 100, false, 64>"
+    plan.rows_setup([c["chr_id"] for c in ctgs], [c["chr_start"] for c in ctgs], 0.2)
+    for rep in range(2):
+        plan.run()
+        plan.rows_begin()
+        text, off = plan.rows_end()
+    pk = plan.peaks()
+    exp = _host_rows(ctgs, pk, 100, 1, 0.2)
+    got = [text[int(off[c]):int(off[c + 1])].decode() for c in range(len(ctgs))]
+    assert got == exp
+    for c in (0, len(ctgs) // 2, len(ctgs) - 1):
+        _, _, osig = ora.wave_windows(bytes(ctgs[c]["seq"]), 100, 1, 100, 3.0, 1.0)
+        mine = pk[pk["ctg"] == c]
+        idx = np.flatnonzero(osig)
+        assert np.array_equal(mine["window"], idx) and np.array_equal(mine["signal"], osig[idx])
+    plan.close()
+    ss.close()
+
+
 def test_device_rows_of_several_plans_in_flight(eng, s288c):
     """rows_begin of three plans on three lanes before the first rows_end: every plan gets its own text."""
     batches = [all_ctgs(s288c, piece=40000)[k::3] for k in range(3)]
