@@ -933,7 +933,26 @@ std::vector<std::string> sw_proc_ctgs(gams_gpu_t *h, const std::vector<Ctg> &ctg
             const int rc = gams_gpu_sw_text(h, sg.s, n, index.data(), chr.data(), chr_start.data(), feat_off.data(), fs.data(),
                                             fe.data(), ids.data(), a.size, a.max, a.resize, &text, &tbytes, &toff, &nrows);
             if (rc == GAMS_OK) {
-                for (uint32_t k = 0; k < n; ++k) out[todo[b + k]].assign(text + toff[k], text + toff[k + 1]);
+                // proc_ctg's Strings: slices of the page-locked text, copied by a few host threads (one thread moves
+                // ~10 GB/s; 313 MB for the 4.1 M rows of a 30-Mb chromosome)
+                const unsigned T = (unsigned)std::max<uint64_t>(
+                    1, std::min<uint64_t>({16, std::thread::hardware_concurrency(), (uint64_t)n, tbytes / (4u << 20) + 1}));
+                std::atomic<uint32_t> next{0};
+                std::vector<std::exception_ptr> errs(T);
+                auto work = [&](unsigned t) {
+                    try {
+                        for (uint32_t k = next.fetch_add(1); k < n; k = next.fetch_add(1))
+                            out[todo[b + k]].assign(text + toff[k], text + toff[k + 1]);
+                    } catch (...) {
+                        errs[t] = std::current_exception();
+                    }
+                };
+                std::vector<std::thread> pool;
+                for (unsigned t = 1; t < T; ++t) pool.emplace_back(work, t);
+                work(0);
+                for (auto &th : pool) th.join();
+                for (auto &er : errs)
+                    if (er) std::rethrow_exception(er);
                 b = e;
                 continue;
             }
