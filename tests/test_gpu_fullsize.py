@@ -272,3 +272,28 @@ def test_tapered_launch_equals_plain(eng):
         plan.set_taper(2)
     plan.close()
     ss.close()
+
+
+def test_step1_rows_and_peaks_over_a_long_tile_table(eng):
+    """A 60-Mb chromosome at step 1 in one-wave tiles: 35,000 tiles, so the exclusive prefix over the tile counts (and the
+    one inside the device-rows graph) takes the three-launch span form (wave_offsets_sum / base / scan_kernel).  Peaks
+    and TSV text must equal those of the same pass in 256-thread tiles (8,500 tiles: the one-workgroup prefix), whose
+    peaks test_config3_step1_geometry_one_chromosome holds against the oracle."""
+    ctgs = synth.gen_ctgs("1", synth.chromosome(60_000_000, 1), piece=1000000)
+    ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])
+    got = {}
+    for threads in (0, 256):
+        plan = engine.WavePlan(eng, ss, 100, 1, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS)
+        plan.set_threads(threads)
+        assert plan.kernel_name().endswith(", 64>") == (threads == 0)
+        plan.rows_setup([c["chr_id"] for c in ctgs], [c["chr_start"] for c in ctgs], 0.2)
+        for rep in range(2):                     # (the second pass copies the text speculatively)
+            plan.run()
+            plan.rows_begin()
+            text, off = plan.rows_end()
+        got[threads] = (bytes(text), off.copy(), plan.peaks().copy())
+        plan.close()
+    ss.close()
+    assert got[0][2].size > 500_000
+    assert np.array_equal(got[0][2], got[256][2])
+    assert got[0][0] == got[256][0] and np.array_equal(got[0][1], got[256][1])
