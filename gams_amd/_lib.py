@@ -75,6 +75,7 @@ PROTOTYPES = {
     "gams_wave_dense": (C.c_int, [_VP, _VP, C.c_uint32, _VP, _VP]),
     "gams_wave_plan_set_tile": (C.c_int, [_VP, _VP, C.c_uint32]),
     "gams_wave_plan_set_threads": (C.c_int, [_VP, _VP, C.c_uint32]),
+    "gams_wave_plan_settled": (C.c_int, [_VP, _VP, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "gams_wave_exact_count": (C.c_int, [_VP, _VP, C.POINTER(C.c_uint64)]),
     "gams_wave_plan_set_guard": (C.c_int, [_VP, _VP, C.c_float, C.c_int]),
     "gams_wave_plan_set_stamps": (C.c_int, [_VP, _VP, C.c_int]),

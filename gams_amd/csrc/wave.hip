@@ -96,6 +96,7 @@ struct gams_wave_plan {
     size_t d_jtiles_bytes = 0;
     uint32_t n_jtiles = 0;
     float *d_xtab = nullptr;      // repair: xtab[k] = k as f32 / size as f32, [size + 1] (inside arena_fixed)
+    bool jac0 = false;            // repair with influence == 0: fill-forward filter + freeze guess (jac0_* kernels)
     bool direct = false;          // halo beyond a tile: one lane per window, no tiling (wave_direct_*_kernel)
     bool wide = false, k16 = false;
     int fast_w = 0;               // W of wave_fast_kernel (0: generic wave_tile_kernel)
@@ -125,6 +126,8 @@ struct gams_wave_plan {
         size_t d_dense_cnt_bytes = 0, d_dense_sig_bytes = 0, d_filtered_bytes = 0;
         uint8_t *d_jac = nullptr;               // repair: filtered[] | dirty blocks | control words (one pooled block)
         size_t d_jac_bytes = 0;
+        bool jac0_table = false;                // influence == 0: the freeze table of this way has been filled
+        bool jac_serial = false;                // the last pass was handed to the one-wavefront-per-ctg recurrence
         unsigned long long *h_ctl = nullptr;    // page-locked copy of the control words, made behind every batch of sweeps
         size_t h_ctl_bytes = 0;
         uint32_t jac_sweeps = 0;                // sweeps queued for the way's current pass
@@ -501,9 +504,14 @@ struct JacBufs {
     float *f;                        // filtered[], one per row
     uint32_t *fblk;                  // per block of kJacTile rows: 1 + the sweep in which filtered last changed there
     unsigned long long *ctl;         // kJacWords control words
+    // influence == 0 only
+    int32_t *lastu, *tile_last;
+    unsigned long long *freeze;
+    int8_t *ftab;
+    uint8_t *frow;
     size_t bytes;
 };
-JacBufs wave_jac_carve(uint8_t *base, uint64_t total_windows) {
+JacBufs wave_jac_carve(uint8_t *base, uint64_t total_windows, const gams_wave_plan_t *p = nullptr) {
     size_t o = 0;
     auto take = [&](size_t b) {
         uint8_t *q = base ? base + o : nullptr;
@@ -514,6 +522,14 @@ JacBufs wave_jac_carve(uint8_t *base, uint64_t total_windows) {
     z.f = reinterpret_cast<float *>(take(std::max<uint64_t>(total_windows, 1) * 4));
     z.fblk = reinterpret_cast<uint32_t *>(take((size_t)(total_windows / kJacTile + 2) * 4));
     z.ctl = reinterpret_cast<unsigned long long *>(take(kJacWords * 8));
+    if (p && p->jac0) {
+        const size_t size1 = (size_t)p->prm.size + 1;
+        z.lastu = reinterpret_cast<int32_t *>(take(std::max<uint64_t>(total_windows, 1) * 4));
+        z.tile_last = reinterpret_cast<int32_t *>(take(std::max<size_t>(p->n_jtiles, 1) * 4));
+        z.freeze = reinterpret_cast<unsigned long long *>(take(std::max<size_t>(p->set->n_ctg, 1) * 2 * 8));
+        z.ftab = reinterpret_cast<int8_t *>(take(size1 * size1));
+        z.frow = reinterpret_cast<uint8_t *>(take(size1));
+    }
     z.bytes = o;
     return z;
 }
@@ -542,7 +558,7 @@ int wave_alloc_ways(gams_gpu_t *h, gams_wave_plan_t *p) {
             GAMS_HIP(h, gams_pool_alloc(h, false, base * sizeof(float), reinterpret_cast<void **>(&w.d_filtered),
                                         &w.d_filtered_bytes));
         if (p->repair && !w.d_jac) {
-            GAMS_HIP(h, gams_pool_alloc(h, false, wave_jac_carve(nullptr, p->total_windows).bytes,
+            GAMS_HIP(h, gams_pool_alloc(h, false, wave_jac_carve(nullptr, p->total_windows, p).bytes,
                                         reinterpret_cast<void **>(&w.d_jac), &w.d_jac_bytes));
             GAMS_HIP(h, gams_pool_alloc(h, true, kJacWords * 8, reinterpret_cast<void **>(&w.h_ctl), &w.h_ctl_bytes));
         }
@@ -638,6 +654,7 @@ int gams_wave_plan_create(gams_gpu_t *h, gams_seqset_t *s, const gams_wave_param
     // influence != 1: guess-and-iterate while a tile's history (256 + lag + 1 floats) fits a comfortable share of the
     // LDS; the one-wavefront-per-ctg recurrence beyond that
     p->repair = p->serial && params->lag >= 2 && params->lag <= 16000;
+    p->jac0 = p->repair && params->influence == 0.0f && params->size <= 400;   // (a (size + 1)^2 table)
     int rc = wave_build_geometry(h, p, 0);
     if (rc != GAMS_OK) {
         delete p;
@@ -789,7 +806,7 @@ constexpr uint32_t kJacFirstBatch = 6;      // sweeps queued with the pass (3-5 
 
 static JacArgs wave_jac_args(gams_wave_plan_t *p, uint32_t k) {
     gams_wave_plan::Way &w = p->way[k];
-    const JacBufs z = wave_jac_carve(w.d_jac, p->total_windows);
+    const JacBufs z = wave_jac_carve(w.d_jac, p->total_windows, p);
     JacArgs a{};
     a.tiles = p->d_jtiles;
     a.n_tiles = p->n_jtiles;
@@ -803,6 +820,13 @@ static JacArgs wave_jac_args(gams_wave_plan_t *p, uint32_t k) {
     a.sweep = 0;
     a.thr = p->prm.threshold;
     a.influence = p->prm.influence;
+    a.lastu = z.lastu;
+    a.tile_last = z.tile_last;
+    a.freeze = z.freeze;
+    a.ftab = z.ftab;
+    a.frow = z.frow;
+    a.size1 = (uint32_t)p->prm.size + 1u;
+    a.n_ctg = p->set->n_ctg;
     return a;
 }
 
@@ -825,11 +849,27 @@ static int wave_jac_sweeps(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k, uint3
     const unsigned grid = std::max(p->n_jtiles, 1u);
     const size_t lds = ((size_t)kJacTile + a.lag + 1) * sizeof(float);
     GAMS_HIP(h, gams_lds_attr(h, reinterpret_cast<const void *>(jac_eval_kernel), lds));
-    if (first) hipLaunchKernelGGL(jac_init_kernel, dim3(grid), dim3(256), 0, st, a);
+    if (first) {
+        hipLaunchKernelGGL(jac_init_kernel, dim3(grid), dim3(256), 0, st, a);
+        if (p->jac0 && !w.jac0_table) {
+            // the decisions behind a freeze point, once per way (the parameters belong to the plan)
+            GAMS_HIP(h, hipMemsetAsync(const_cast<uint8_t *>(a.frow), 1, a.size1, st));
+            hipLaunchKernelGGL(jac0_table_kernel, dim3((a.size1 * a.size1 + 255u) / 256u), dim3(256), 0, st,
+                               const_cast<int8_t *>(a.ftab), const_cast<uint8_t *>(a.frow), a.xtab, a.size1, a.lag, a.thr);
+            w.jac0_table = true;
+        }
+    }
+    const uint32_t max_sweeps = p->jac0 ? kJacMaxSweeps0 : kJacMaxSweeps;
     if (p->n_jtiles)
-        for (uint32_t i = 0; i < n && w.jac_sweeps < kJacMaxSweeps; ++i, ++w.jac_sweeps) {
+        for (uint32_t i = 0; i < n && w.jac_sweeps < max_sweeps; ++i, ++w.jac_sweeps) {
             a.sweep = w.jac_sweeps;
-            hipLaunchKernelGGL(jac_filter_kernel, dim3(grid), dim3(256), 0, st, a);
+            if (p->jac0) {
+                const unsigned g0 = (grid + kJac0Group - 1u) / kJac0Group;
+                hipLaunchKernelGGL(jac0_scan_kernel, dim3(g0), dim3(256), 0, st, a);
+                hipLaunchKernelGGL(jac0_fill_kernel, dim3(g0), dim3(256), 0, st, a);
+            } else {
+                hipLaunchKernelGGL(jac_filter_kernel, dim3(grid), dim3(256), 0, st, a);
+            }
             hipLaunchKernelGGL(jac_eval_kernel, dim3(grid), dim3(256), lds, st, a);
         }
     GAMS_HIP(h, hipGetLastError());
@@ -853,7 +893,7 @@ static int wave_jac_settle(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
         for (uint32_t i = 0; i < w.jac_sweeps && !fixed; ++i) fixed = w.h_ctl[i] == 0ull;
         const bool abandon = w.h_ctl[kJacAbandon] != 0ull;
         if (fixed && !abandon) break;
-        if (abandon || w.jac_sweeps >= kJacMaxSweeps) {
+        if (abandon || w.jac_sweeps >= (p->jac0 ? kJacMaxSweeps0 : kJacMaxSweeps)) {
             const gams_wave_params_t &q = p->prm;
             const uint32_t n = p->set->n_ctg;
             if (q.lag + 1u <= kSerialRing) {
@@ -870,12 +910,26 @@ static int wave_jac_settle(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
             int rc = wave_compact_dense(h, p, k, st);
             if (rc != GAMS_OK) return rc;
             GAMS_HIP(h, hipStreamSynchronize(st));
+            w.jac_serial = true;
             break;
         }
-        int rc = wave_jac_sweeps(h, p, k, 8, false);
+        // (influence 0: the dense regime takes tens of sweeps, a host round trip per batch: 8, 16, 32, 32, ...)
+        int rc = wave_jac_sweeps(h, p, k, !p->jac0 ? 8u : w.jac_sweeps < 14u ? 8u : w.jac_sweeps < 30u ? 16u : 32u, false);
         if (rc != GAMS_OK) return rc;
     }
     w.jac_settled = true;
+    return GAMS_OK;
+}
+
+int gams_wave_plan_settled(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t *sweeps, int *serial) {
+    if (!h || !p || !sweeps || !serial) return gams_fail(h, GAMS_EINVAL, "wave_plan_settled: null argument");
+    if (!p->ran) return gams_fail(h, GAMS_ESTATE, "wave_plan_settled: no run to read");
+    GAMS_HIP(h, hipSetDevice(h->device));
+    const uint32_t k = wave_read_way_index(p);
+    const int rc = wave_jac_settle(h, p, k);
+    if (rc != GAMS_OK) return rc;
+    *sweeps = p->repair ? p->way[k].jac_sweeps : 0u;
+    *serial = p->repair ? (p->way[k].jac_serial ? 1 : 0) : (p->serial ? 1 : 0);
     return GAMS_OK;
 }
 
@@ -1020,6 +1074,7 @@ static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
         // (wave_jac_settle) and queues more sweeps if it did not
         w.jac_sweeps = 0;
         w.jac_settled = false;
+        w.jac_serial = false;
         rc = wave_jac_sweeps(h, p, k, kJacFirstBatch, true);
         if (rc != GAMS_OK) return rc;
     } else if (p->serial) {

@@ -136,6 +136,12 @@ class WavePlan:
         """windows per workgroup (0: the library's choice); 1024 / 2048 / 3072 / 5120 / 7168 select the fast kernels' W"""
         self.eng.check(self.eng.lib.gams_wave_plan_set_tile(self.eng.h, self.p, tile_windows))
 
+    def settled(self):
+        """influence != 1: (sweeps of guess-and-iterate the selected pass took, handed to the serial recurrence?)"""
+        n, ser = C.c_uint32(), C.c_int()
+        self.eng.check(self.eng.lib.gams_wave_plan_settled(self.eng.h, self.p, C.byref(n), C.byref(ser)))
+        return int(n.value), bool(ser.value)
+
     def set_threads(self, threads):
         """threads per workgroup of the step-1 W = 28 kernels: 64 / 128 / 256 (0: the library's choice)"""
         self.eng.check(self.eng.lib.gams_wave_plan_set_threads(self.eng.h, self.p, threads))

@@ -42,6 +42,10 @@ int gams_wave_plan_set_queue_threads(gams_gpu_t *h, gams_wave_plan_t *plan, uint
  * benchmark line name the row of the profile its launch duration must agree with.  Follows the plan's
  * current settings (set_tile / set_taper / the seqset's size).  NUL-terminated, truncated to n. */
 int gams_wave_plan_kernel_name(gams_gpu_t *h, gams_wave_plan_t *plan, char *buf, size_t n);
+/* influence != 1: how the selected pass reached the reference's answer -- the sweeps of guess-and-iterate it took
+ * (waits for them like every reader of the pass), and whether it was handed to the one-wavefront-per-ctg recurrence
+ * instead (serial = 1).  influence == 1: 0 sweeps, serial = 0. */
+int gams_wave_plan_settled(gams_gpu_t *h, gams_wave_plan_t *plan, uint32_t *sweeps, int *serial);
 
 /* Tuning/diagnostics: windows per tile (0 = library default), and how many
  * windows of the last run took the exact-order f32 re-evaluation. */

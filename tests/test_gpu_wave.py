@@ -782,6 +782,42 @@ def test_thresholding_sample_through_the_device(eng):
         ss.close()
 
 
+@pytest.mark.parametrize("size,step,lag,thr", [(100, 10, 100, 2.0), (100, 10, 100, 1.0), (100, 10, 100, 3.0), (100, 1, 100, 2.0),
+                                               (100, 10, 30, 1.5), (100, 5, 200, 2.5), (50, 7, 33, 0.5), (100, 10, 100, 0.05),
+                                               (200, 20, 64, 2.0), (100, 10, 2, 2.0), (100, 10, 3, 1.0)])
+def test_influence_zero_freezes_and_the_sweeps_follow(eng, s288c, size, step, lag, thr):
+    """influence 0: once `lag` windows in a row have signalled filtered[] never moves again and every later window signals
+    unless its count equals the frozen one -- the dense regime that plain sweeps cannot settle.  The jac0_* kernels (fill-
+    forward filter, the freeze guess from a (size + 1)^2 table) reach the reference's answer WITHOUT the one-wavefront-
+    per-ctg recurrence: counts, signals, peaks against the oracle on ragged ctgs (real sequence, synthetic, N runs,
+    homopolymer stretches), and the pass reports how it settled."""
+    pool = [bytes(s288c["I"][:150_000]), synth(60_000, 41).tobytes(), bytes(s288c["Mito"][:30_000]),
+            synth(9_000, 51, gc=0.5, nrate=0.02).tobytes(), (b"ACGT" * 3000 + b"N" * 500 + b"GGCC" * 2000 + b"AT" * 4000)]
+    seqs = [sq for sq in pool if (len(sq) - size) // step + 1 >= lag]
+    ss = engine.SeqSet(eng, seqs)
+    plan = engine.WavePlan(eng, ss, size, step, lag, thr, 0.0, flags=_lib.WAVE_PEAKS | _lib.WAVE_DENSE)
+    frozen = 0
+    for rep in range(2):
+        plan.run()
+        sweeps, serial = plan.settled()
+        assert not serial and 0 < sweeps <= 240, (sweeps, serial)
+    pk = plan.peaks()
+    for c, sq in enumerate(seqs):
+        ocnt, _, osig = ora.wave_windows(sq, size, step, lag, thr, 0.0)
+        cnt, sig = plan.dense(c)
+        assert np.array_equal(cnt, ocnt)
+        bad = np.flatnonzero(sig.astype(np.int32) != osig)
+        assert bad.size == 0, (c, bad[:5], sig[bad[:5]], osig[bad[:5]])
+        mine = pk[pk["ctg"] == c]
+        idx = np.flatnonzero(osig)
+        assert np.array_equal(mine["window"], idx) and np.array_equal(mine["signal"], osig[idx])
+        frozen += int(np.count_nonzero(osig) > osig.size // 2)
+    if thr <= 2.0 and lag >= 30:
+        assert frozen > 0                      # (the case this test is about did occur)
+    plan.close()
+    ss.close()
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_influence_fuzz_against_the_oracle(eng, s288c, seed):
     """Random (size, step, lag, threshold, influence) with influence != 1 on ragged batches: thresholds low enough

@@ -26,8 +26,10 @@ def rate(ss, n_ctg, infl, thr=3.0, lag=100, step=10):
         plan.peaks_count()          # influence != 1 settles (more sweeps if needed) when somebody reads the pass
     eng.sync()
     ms = (time.perf_counter() - t0) / reps * 1e3
+    sweeps, serial = plan.settled()
     print(f"influence {infl} threshold {thr} lag {lag} step {step}: {n_ctg} ctgs, {plan.total_windows} windows, {ms:.3f} ms per pass, "
-          f"{plan.total_windows / ms / 1e3:.1f} M windows/s, {plan.peaks().size} peaks ({plan.kernel_name()})", flush=True)
+          f"{plan.total_windows / ms / 1e3:.1f} M windows/s, {plan.peaks().size} peaks ({plan.kernel_name()}; "
+          f"{sweeps} sweeps{', then the serial recurrence' if serial else ''})", flush=True)
     plan.close()
 
 
