@@ -127,10 +127,31 @@ __global__ __launch_bounds__(256) void jac_filter_kernel(const JacArgs a) {
     }
 }
 
+// inclusive maximum over the 256 threads of the workgroup up to each thread; total = the workgroup's maximum
+__device__ __forceinline__ int jac0_block_max_scan(int v, int *ws, int &total) {
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d, 64);
+        if ((int)lane >= d) v = max(v, o);
+    }
+    if (lane == 63u) ws[wv] = v;
+    __syncthreads();
+    const int w0 = ws[0], w1 = ws[1], w2 = ws[2], w3 = ws[3];
+    __syncthreads();
+    const int before = wv == 0 ? -1 : wv == 1 ? w0 : wv == 2 ? max(w0, w1) : max(max(w0, w1), w2);
+    total = max(max(w0, w1), max(w2, w3));
+    return max(v, before);
+}
+
+constexpr uint32_t kJac0InnerFrom = 0;     // influence 0: from this sweep on a dirty tile iterates on itself ...
+constexpr uint32_t kJac0Inner = 32;         // ... up to this many times per sweep
+
 // every window of a tile whose history changed: the reference's decision from filtered[] (stat.rs:30-38, :51-52)
 __global__ __launch_bounds__(256) void jac_eval_kernel(const JacArgs a) {
     extern __shared__ float L[];                               // filtered[w0 - 1 - lag .. w0 + 254]
     __shared__ uint32_t flips_wg;
+    __shared__ float X[kJacTile];                              // influence 0, inner iterations: the tile's data values
+    __shared__ int ws[4];
     if (jac_done(a)) return;
     const JacTile t = a.tiles[blockIdx.x];
     const uint32_t tid = threadIdx.x, lag = a.lag;
@@ -152,7 +173,9 @@ __global__ __launch_bounds__(256) void jac_eval_kernel(const JacArgs a) {
     __syncthreads();
     const uint32_t i = t.w0 + tid;
     uint32_t flipped = 0u;
-    if (i < t.n_win && i >= lag) {
+    const bool tested = i < t.n_win && i >= lag;
+    const float x = i < t.n_win ? a.xtab[a.cnt[t.win_base + i]] : 0.0f;
+    auto decide = [&]() -> int {
         const float *h = L + tid + (i == lag ? 1u : 0u);        // window i == lag averages [0, lag) like window lag + 1
         const float len = (float)lag;
         float sum = 0.0f;
@@ -166,9 +189,32 @@ __global__ __launch_bounds__(256) void jac_eval_kernel(const JacArgs a) {
             sq = sq + d * d;                                                                   // stat.rs:12
         }
         const float sd = sqrtf(sq / (len - 1.0f));                                             // stat.rs:13
-        const float x = a.xtab[a.cnt[t.win_base + i]];
         int s = 0;
         if (fabsf(x - mean) > a.thr * sd) s = x > mean ? 1 : -1;                               // stat.rs:36-38
+        return s;
+    };
+    int s = tested ? decide() : 0;
+    // Influence 0, late sweeps: what is left then are the runs in front of the freeze points, which a sweep extends by
+    // the few windows whose history has just become right.  The tile repeats the two steps on itself -- filtered[] of its
+    // own windows from the decisions just made (a fill-forward inside the tile, in front of it L[lag] as it stands),
+    // then the decisions again -- until nothing changes or kJac0Inner times: another guess, like every state of the
+    // iteration; the flips are counted against the signals the sweep started from.
+    if (a.lastu != nullptr && a.sweep >= kJac0InnerFrom) {
+        X[tid] = x;
+        for (uint32_t it = 1; it < kJac0Inner; ++it) {
+            int tot;
+            const int last = jac0_block_max_scan(i < t.n_win && s == 0 ? (int)tid : -1, ws, tot);
+            const float fnew = last >= 0 ? X[last] : L[lag];
+            __syncthreads();
+            L[lag + 1u + tid] = fnew;
+            __syncthreads();
+            const int s2 = tested ? decide() : 0;
+            const int changed = s2 != s;
+            s = s2;
+            if (!__syncthreads_or(changed)) break;
+        }
+    }
+    if (tested) {
         int8_t *sp = a.sig + t.win_base + i;
         if (*sp != (int8_t)s) {
             *sp = (int8_t)s;
@@ -216,22 +262,6 @@ __global__ __launch_bounds__(256) void jac0_table_kernel(int8_t *ftab, uint8_t *
     if (fabsf(x - mean) > thr * sd) sg = x > mean ? 1 : -1;                                    // stat.rs:36-38
     ftab[q] = (int8_t)sg;
     if (sg == 0 && k != kc) frow[kc] = 0;          // (frow starts as all ones; every writer stores the same value)
-}
-
-// inclusive maximum over the 256 threads of the workgroup up to each thread; total = the workgroup's maximum
-__device__ __forceinline__ int jac0_block_max_scan(int v, int *ws, int &total) {
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(v, d, 64);
-        if ((int)lane >= d) v = max(v, o);
-    }
-    if (lane == 63u) ws[wv] = v;
-    __syncthreads();
-    const int w0 = ws[0], w1 = ws[1], w2 = ws[2], w3 = ws[3];
-    __syncthreads();
-    const int before = wv == 0 ? -1 : wv == 1 ? w0 : wv == 2 ? max(w0, w1) : max(max(w0, w1), w2);
-    total = max(max(w0, w1), max(w2, w3));
-    return max(v, before);
 }
 
 // (1) the guess behind the ctg's freeze point, then the last window of the tile, up to each lane, that does not signal
