@@ -1350,8 +1350,7 @@ int gams_wave_plan_kernel_name(gams_gpu_t *h, gams_wave_plan_t *p, char *buf, si
         name = std::string("wave_fast_taper_kernel<100, 10, 100, ") + nt + ">";
     else if (p->fast_w) {
         const std::string prm = baked ? "100, " + std::to_string(q.step) + (kind == 1 ? ", 100, " : ", 0, ") : "0, 0, 0, ";
-        name = "wave_fast_kernel<" + std::to_string(p->fast_w) + ", " + prm + nt +
-               (p->nth != 256 ? ", " + std::to_string(p->nth) : std::string()) + ">";
+        name = "wave_fast_kernel<" + std::to_string(p->fast_w) + ", " + prm + nt + ", " + std::to_string(p->nth) + ">";
     } else
         name = std::string("wave_tile_kernel<") + (p->k16 ? "unsigned short, " : "unsigned char, ") + (p->wide ? "true>" : "false>");
     std::snprintf(buf, n, "%s", name.c_str());

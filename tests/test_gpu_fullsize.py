@@ -252,7 +252,7 @@ def test_tapered_launch_equals_plain(eng):
     tapered = plan.peaks()
     n_exact = plan.exact_count()
     plan.set_taper(0)
-    assert plan.kernel_name() == "wave_fast_kernel<12, 100, 10, 100, true>"
+    assert plan.kernel_name() == "wave_fast_kernel<12, 100, 10, 100, true, 256>"
     plan.run()
     plain = plan.peaks()
     assert np.array_equal(tapered, plain)

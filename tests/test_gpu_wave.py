@@ -621,13 +621,13 @@ def test_plan_kernel_name_follows_the_plan(eng):
         plan.close()
     ss.close()
     # a 300-kb ctg is a handful of tiles: the smallest tile, which is baked for the headline parameters only
-    assert names[(100, 10, 100, 1.0)] == "wave_fast_kernel<4, 100, 10, 100, false>"
-    assert names["headline, 3072"] == "wave_fast_kernel<12, 100, 10, 100, false>"
-    assert names[(100, 1, 100, 1.0)] == "wave_fast_kernel<4, 0, 0, 0, false>"
-    assert names["step 1, 5120"] == "wave_fast_kernel<20, 100, 1, 100, false>"
+    assert names[(100, 10, 100, 1.0)] == "wave_fast_kernel<4, 100, 10, 100, false, 256>"
+    assert names["headline, 3072"] == "wave_fast_kernel<12, 100, 10, 100, false, 256>"
+    assert names[(100, 1, 100, 1.0)] == "wave_fast_kernel<4, 0, 0, 0, false, 256>"
+    assert names["step 1, 5120"] == "wave_fast_kernel<20, 100, 1, 100, false, 256>"
     assert names["step 1, 7168"] == "wave_fast_kernel<28, 100, 1, 100, false, 64>"       # W = 28: a tile per wave
-    assert names["step 1, 7168, four waves"] == "wave_fast_kernel<28, 100, 1, 100, false>"
-    assert names[(50, 7, 33, 1.0)] == "wave_fast_kernel<4, 0, 0, 0, false>"
+    assert names["step 1, 7168, four waves"] == "wave_fast_kernel<28, 100, 1, 100, false, 256>"
+    assert names[(50, 7, 33, 1.0)] == "wave_fast_kernel<4, 0, 0, 0, false, 256>"
     assert names[(100, 10, 100, 0.5)] == "jac_eval_kernel"
     assert names[(100, 1000, 100, 1.0)].startswith("wave_direct_count_kernel")
 
@@ -699,7 +699,7 @@ def test_step1_tiles_of_one_two_or_four_waves(eng, s288c, threads):
                 assert np.array_equal(mine["window"], idx) and np.array_equal(mine["signal"], osig[idx]), (threads, lag, c)
             plan.close()
         ss.close()
-    tag = "" if threads == 256 else f", {threads}"
+    tag = f", {threads}"
     assert f"wave_fast_kernel<28, 100, 1, 100, false{tag}>" in seen and f"wave_fast_kernel<28, 100, 1, 0, false{tag}>" in seen, seen
 
 
