@@ -370,6 +370,15 @@ int wave_build_geometry(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t tw_req) {
             // (diagnostics: the headline kernel in workgroups of one or two waves, on request only -- see DESIGN 3.1)
             if (pick == 12 && q.size == 100 && q.step == 10 && q.lag == 100 && (p->nth_req == 64 || p->nth_req == 128))
                 p->nth = p->nth_req;
+            // The W = 20 step-5 kernel (lag as an argument) sits between the two regimes: tiles of TWO waves for peaks-only
+            // plans over 4,096 such tiles or more (384 Mb 98.0 -> 89.8 us, one wave 94.8; 120 Mb 38.9 -> 38.3 us;
+            // gpurun_out/r3_ab_threads5.log)
+            if (pick == 20 && q.size == 100 && q.step == 5 && wave_baked_kind(q, 20) == 2) {
+                const bool narrow_ok = !(p->flags & GAMS_WAVE_DENSE) && !p->serial;
+                const uint32_t want = p->nth_req ? p->nth_req
+                                      : narrow_ok && p->total_windows / (128u * 20u) >= 4096 ? 128u : 256u;
+                if ((want == 64 || want == 128) && q.lag + 1u <= (want / 2u) * 20u) p->nth = want;
+            }
             // baked kernels: the tile's windows plus the lag+1 in front fill nth*W slots exactly
             p->tw = wave_is_baked(q, pick) ? p->nth * pick - q.lag - 1u : 256u * pick;
             p->max_win = p->tw + q.lag + 1;
@@ -1031,7 +1040,11 @@ static int wave_pass_on_way(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t k) {
         case 820: GAMS_RL(8, 20); break;
         case 1220: GAMS_RL(12, 20); break;
         case 2001: GAMS_RL(20, 1); break;
-        case 2005: GAMS_RL(20, 5); break;
+        case 2005:
+            rc = p->nth == 64    ? wave_launch_fast<20, 100, 5, 0, 64>(h, p, a, st)
+                 : p->nth == 128 ? wave_launch_fast<20, 100, 5, 0, 128>(h, p, a, st)
+                                 : wave_launch_fast<20, 100, 5, 0>(h, p, a, st);
+            break;
         case 2801:
             rc = p->nth == 64    ? wave_launch_fast<28, 100, 1, 0, 64>(h, p, a, st)
                  : p->nth == 128 ? wave_launch_fast<28, 100, 1, 0, 128>(h, p, a, st)

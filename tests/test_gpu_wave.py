@@ -703,6 +703,34 @@ def test_step1_tiles_of_one_two_or_four_waves(eng, s288c, threads):
     assert f"wave_fast_kernel<28, 100, 1, 100, false{tag}>" in seen and f"wave_fast_kernel<28, 100, 1, 0, false{tag}>" in seen, seen
 
 
+@pytest.mark.parametrize("threads", [64, 128, 256])
+def test_step5_tiles_of_one_two_or_four_waves(eng, s288c, threads):
+    """The W = 20 step-5 kernel (size and step baked, the lag an argument) in tiles of 64, 128 or 256 threads (a peaks-only
+    plan over a genome takes 128): counts, signals, peaks against the oracle on ragged ctgs at the lags around the
+    narrow tile's boundaries (lag + 1 <= threads / 2 * 20, the blocks of 20 slots)."""
+    pool = [bytes(s288c["I"][:200_000]), synth(81_234, 5).tobytes(), bytes(s288c["Mito"][:30_000]), synth(8_777, 6).tobytes(),
+            synth((1_280 - 101) * 5 + 99, 7).tobytes(), synth((1_280 - 100) * 5 + 99, 8).tobytes()]
+    half = min(threads // 2 * 20, 656)              # (lag * size beyond 16 bits leaves the fast kernels)
+    for lag in [100, 2, 19, 20, 21, 50, 200, 255, half - 2, half - 1]:
+        seqs = [sq for sq in pool if (len(sq) - 100) // 5 + 1 >= lag]
+        ss = engine.SeqSet(eng, seqs)
+        plan = engine.WavePlan(eng, ss, 100, 5, lag, 3.0 if lag != 50 else 1.5, 1.0, flags=_lib.WAVE_PEAKS | _lib.WAVE_DENSE,
+                               tile_windows=5120)
+        plan.set_threads(threads)
+        assert plan.kernel_name() == f"wave_fast_kernel<20, 100, 5, 0, false, {threads}>", (lag, plan.kernel_name())
+        plan.run()
+        pk = plan.peaks()
+        for c, sq in enumerate(seqs):
+            ocnt, _, osig = ora.wave_windows(sq, 100, 5, lag, 3.0 if lag != 50 else 1.5, 1.0)
+            cnt, sig = plan.dense(c)
+            assert np.array_equal(cnt, ocnt) and np.array_equal(sig.astype(np.int32), osig), (threads, lag, c)
+            mine = pk[pk["ctg"] == c]
+            idx = np.flatnonzero(osig)
+            assert np.array_equal(mine["window"], idx) and np.array_equal(mine["signal"], osig[idx]), (threads, lag, c)
+        plan.close()
+        ss.close()
+
+
 @pytest.mark.parametrize("threads", [64, 128])
 def test_headline_kernel_in_narrow_workgroups_on_request(eng, s288c, threads):
     """The W = 12 headline kernel also compiles for one or two waves per tile (a diagnostic: it is HBM bound and loses
