@@ -297,3 +297,22 @@ def test_step1_rows_and_peaks_over_a_long_tile_table(eng):
     assert got[0][2].size > 500_000
     assert np.array_equal(got[0][2], got[256][2])
     assert got[0][0] == got[256][0] and np.array_equal(got[0][1], got[256][1])
+
+
+def test_step5_two_wave_tiles_on_a_chromosome(eng):
+    """size 100 / step 5 / lag 200 (the reference's own benchmark parameters, doc/benchmark/Atha.md:55) over a 60-Mb
+    chromosome: a peaks-only plan runs W = 20 tiles of two waves there; every peak against the oracle, and against the
+    same pass in four-wave tiles."""
+    ctgs = synth.gen_ctgs("5", synth.chromosome(60_000_000, 5), piece=1000000)
+    ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])
+    plan = engine.WavePlan(eng, ss, 100, 5, 200, 3.0, 1.0, flags=_lib.WAVE_PEAKS)
+    assert plan.kernel_name() == "wave_fast_kernel<20, 100, 5, 0, false, 128>"
+    plan.run()
+    pk = plan.peaks().copy()
+    plan.set_threads(256)
+    assert plan.kernel_name() == "wave_fast_kernel<20, 100, 5, 0, false, 256>"
+    plan.run()
+    assert np.array_equal(plan.peaks(), pk)
+    plan.close()
+    ss.close()
+    assert np.array_equal(pk, oracle_peaks(ctgs, 100, 5, 200, 3.0))
