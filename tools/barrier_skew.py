@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""When do the four waves of a workgroup reach a barrier of the step-1 wave kernel?  Experimental builds
+"""When do the four waves of a workgroup reach a barrier of the wave kernel (SKEW_STEP=1, the default, or 10)?  Experimental builds
 (tools/ab/bar{1,2,3}.so: lane 0 of wave w stores the shader clock into stamp slot 12 + w in front of the barrier that
 ends phase 1 / phase 2 / at the end of phase 3).  Prints, over all workgroups of one 384-Mb launch: the spread between the
 first and the last wave to arrive, and how long after the PREVIOUS stamp of thread 0 each wave arrived."""
@@ -11,11 +11,14 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gams_amd import _lib, engine, synth  # noqa: E402
 
+STEP = int(os.environ.get("SKEW_STEP", "1"))
 ctgs = synth.genome_ctgs([16_000_000] * 24, 1000000, first_chr_index=500)
 for path, prev, nxt in zip(sys.argv[1:4], (0, 2, 3), (1, 3, 4)):
     eng = engine.Engine(0, lib=_lib.bind(os.path.abspath(path), strict=False))
     ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])
-    plan = engine.WavePlan(eng, ss, 100, 1, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS)
+    plan = engine.WavePlan(eng, ss, 100, STEP, 100, 3.0, 1.0, flags=_lib.WAVE_PEAKS)
+    plan.set_threads(256)
+    plan.set_taper(0)
     for _ in range(3):
         plan.run()
     eng.sync()
