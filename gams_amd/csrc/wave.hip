@@ -796,7 +796,7 @@ int gams_wave_plan_set_threads(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t thre
     if (!h || !p) return gams_fail(h, GAMS_EINVAL, "wave_plan_set_threads: null argument");
     if (threads != 0 && threads != 64 && threads != 128 && threads != 256)
         return gams_fail(h, GAMS_EINVAL, "wave_plan_set_threads: 0 (the library's choice), 64, 128 or 256");
-    p->nth_req = threads == 256 ? 0xFFFFFFFFu : threads;
+    p->nth_req = threads;
     return gams_wave_plan_set_tile(h, p, p->tw_req);
 }
 
