@@ -23,9 +23,11 @@
 // which windows take the exact path).  Parameters whose halo does not fit a tile at all (large
 // steps, very large lags) run untiled: wave_direct_count_kernel + wave_direct_signal_kernel.
 //
-// influence != 1 makes filtered[] (stat.rs:42) a true serial recurrence: those
-// runs use wave_serial_wave_kernel (one wavefront per ctg, exact f32 order; one lane per ctg beyond lag 16383) on the counts of a
-// counts-only tile pass, then wave_compact_kernel.
+// influence != 1 makes filtered[] (stat.rs:42) a serial recurrence per ctg: those plans guess the signals with the
+// influence == 1 kernels and iterate signals -> filtered -> signals to the fixed point, every window in parallel
+// (wave_repair.hpp; influence 0 has its own fill-forward filter and a "freeze" guess), then wave_compact_kernel.  The
+// round-2 form -- wave_serial_wave_kernel, one wavefront per ctg in exact f32 order (one lane per ctg beyond lag
+// 16383) on the counts of a counts-only tile pass -- is what takes over if the sweeps do not settle.
 //
 // Compile with -ffp-contract=off: the exact paths must not fuse (x-m)*(x-m)+acc.
 

@@ -444,10 +444,11 @@ __device__ __forceinline__ void z_decide(float nf, float kkf, float S1f, float S
 }
 
 // =============================================================================
-// wave_fast_tile<W,SIZE,STEP,LAG,NT>: the tile algorithm for 8-bit counts (size <= 255),
+// wave_fast_tile<W,SIZE,STEP,LAG,NT,NTH>: the tile algorithm for 8-bit counts (size <= 255),
 // step <= 32 and 24-bit sums (lag*size <= 65535, lag*size^2 < 2^24), i.e. every BASELINE
-// configuration.  256 threads, W windows per thread; a tile holds 256*W - lag - 1 windows when the
-// parameters are baked in, 256*W otherwise.  wave_fast_kernel runs one tile size per launch,
+// configuration.  NTH threads (256; 64 for the step-1 kernels and 128 for the step-5 one of peaks-only
+// plans: a tile per one or two waves, see NTH below), W windows per thread; a tile holds NTH*W - lag - 1
+// windows when the parameters are baked in, 256*W otherwise.  wave_fast_kernel runs one tile size per launch,
 // wave_fast_taper_kernel W = 12 tiles followed by W = 8 and W = 4 tiles (the launch's tail).
 //
 //   phase 1  tile bytes HBM -> registers (16 B/lane, coalesced; NT: the first and last row with
