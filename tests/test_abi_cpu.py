@@ -62,13 +62,13 @@ def test_window_count_matches_reference_loop():
 
 
 def test_no_gpu_means_loud_failure():
-    import torch
-
-    if torch.cuda.is_available():
-        pytest.skip("a GPU is present")
     lib = _lib.load()
     h = C.c_void_p()
-    assert lib.gams_gpu_create(0, C.byref(h)) == _lib.ENODEV
+    rc = lib.gams_gpu_create(0, C.byref(h))
+    if rc == 0:                                   # (the file is meant for the CPU container)
+        lib.gams_gpu_destroy(h)
+        pytest.skip("a GPU is present")
+    assert rc == _lib.ENODEV
     from gams_amd import engine
 
     with pytest.raises(_lib.GamsError):
