@@ -672,6 +672,31 @@ def main():
                                            "bytes_per_window": 1, "peaks": int(p1.peaks_count())}
                 p1.close()
             ss.close()
+        # --influence other than 1 (stat.rs:42: a recurrence per ctg; guess-and-iterate on the device): ms per pass over the
+        # 59 ctgs of one 30-Mb chromosome, a reader waiting for the fixed point, and how the pass settled
+        if prm["step"] == 10:
+            c30 = synth.gen_ctgs("1", synth.chromosome(30_427_671, 1), piece=500000)
+            ss = engine.SeqSet(eng, [c["seq"] for c in c30])
+            infl = {}
+            for tag, influence, thr in (("influence_0.5", 0.5, 3.0), ("influence_0", 0.0, 3.0), ("influence_0_threshold_2", 0.0, 2.0)):
+                pl = engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS, **dict(prm, influence=influence, threshold=thr))
+                for _ in range(3):
+                    pl.run()
+                    pl.peaks_count()
+                eng.sync()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    pl.run()
+                    n_pk = pl.peaks_count()
+                eng.sync()
+                ms_i = (time.perf_counter() - t0) / 10 * 1e3
+                sweeps, serial = pl.settled()
+                infl[tag] = {"ms_per_pass": ms_i, "windows_per_s": pl.total_windows / (ms_i * 1e-3), "peaks": int(n_pk),
+                             "sweeps_queued": sweeps, "serial_fallback": bool(serial)}
+                pl.close()
+            infl["workload"] = f"{sum(len(c['seq']) for c in c30)} bp, {len(c30)} ctgs: pass + packed peaks in host memory"
+            extra["influence_30Mb"] = infl
+            ss.close()
         out["extra"] = extra
     if rank == 0 and world == 1 and not args.no_secondary:
         out["secondary"] = secondary_metrics(eng)
