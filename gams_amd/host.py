@@ -74,6 +74,8 @@ def load():
     L.gams_host_count_multi.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p]
     L.gams_host_cover_multi.restype = C.c_int
     L.gams_host_cover_multi.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 8 + [C.c_uint64, C.c_void_p]
+    L.gams_host_last_operator_ms.restype = C.c_double
+    L.gams_host_last_operator_ms.argtypes = []
     L.gams_host_sw_multi_timed.restype = C.c_void_p
     L.gams_host_sw_multi_timed.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, sp, sp, ip, ip, C.c_void_p, C.c_char_p,
                                            C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -316,6 +318,11 @@ def sw_multi(engines, ctgs, features_per_ctg, size=100, mx=20, resize=500):
     rows = "\n".join(f"{i}\t{fid}\t{s}\t{e}" for i, fl in enumerate(features_per_ctg) for fid, s, e in fl)
     return _take(load().gams_host_sw_multi(hs, len(engines), n, ids, chrs, st.ctypes.data, en.ctypes.data, seqs,
                                            rows.encode(), size, mx, resize))
+
+
+def last_operator_ms():
+    """ms the last locate / anno call of this thread spent inside the C++ operator (without the binding's copies)"""
+    return float(load().gams_host_last_operator_ms())
 
 
 def sw_multi_timed(engines, ctgs, features_per_ctg, size=100, mx=20, resize=500):

@@ -1071,71 +1071,128 @@ std::vector<std::string> Locator::find(const std::vector<Range> &rgs) {
 }
 
 std::string Locator::locate(const std::vector<std::string> &rgs, bool is_count) {
-    // range strings are parsed and rows are formatted on several host threads (contiguous runs of
-    // lines, concatenated in order); the lookups in between are one device call each
-    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>({8, std::thread::hardware_concurrency(), rgs.size() / 20000}));
+    // Range strings are parsed and rows are formatted on several host threads (contiguous shares of the lines, joined
+    // in order); the lookups in between are one device call each.  Nothing string-valued is kept per line between the
+    // stages: a share keeps (chromosome group, start, end, line number) of its valid ranges, the ctg of a hit is an index
+    // into the ctg table, and the rg group of a ctg is a table by that index (1e6 lines: 169 -> ~40 ms, most of it
+    // Range::from_str).
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>({16, std::thread::hardware_concurrency(), rgs.size() / 20000}));
     auto cut = [&](size_t n, unsigned t) { return n * t / T; };
-    std::vector<std::vector<Range>> vpart(T);
-    std::vector<std::vector<size_t>> spart(T);
+    struct Share {
+        std::vector<uint32_t> grp, qs, qe;
+        std::vector<size_t> src;
+        size_t first = 0;               // position of the share's first valid range in the joined arrays
+        std::string out;
+    };
+    std::vector<Share> sh(T);
     run_shares(T, [&](uint32_t t) {
+        Share &m = sh[t];
+        const std::string *last_chr = nullptr;
+        uint32_t last_grp = UINT32_MAX;
+        std::string keep;
         for (size_t i = cut(rgs.size(), t); i < cut(rgs.size(), t + 1); ++i) {   // locate.rs:111-116
-            Range r = Range::from_str(rgs[i]);
+            const Range r = Range::from_str(rgs[i]);
             if (!r.valid) continue;
-            r.strand.clear();
-            vpart[t].push_back(std::move(r));
-            spart[t].push_back(i);
+            if (!last_chr || r.chr != keep) {                                   // utils.rs:11-13 (runs of one chromosome are the rule)
+                auto it = chr_group_.find(r.chr);
+                last_grp = it == chr_group_.end() ? UINT32_MAX : it->second;
+                keep = r.chr;
+                last_chr = &keep;
+            }
+            m.grp.push_back(last_grp);
+            m.qs.push_back((uint32_t)r.start);                                  // utils.rs:16: find(start, end)
+            m.qe.push_back((uint32_t)r.end);
+            m.src.push_back(i);
         }
     });
-    std::vector<Range> valid;
-    std::vector<size_t> src;
-    for (unsigned t = 0; t < T; ++t) {
-        valid.insert(valid.end(), std::make_move_iterator(vpart[t].begin()), std::make_move_iterator(vpart[t].end()));
-        src.insert(src.end(), spart[t].begin(), spart[t].end());
+    size_t nq = 0;
+    for (Share &m : sh) {
+        m.first = nq;
+        nq += m.src.size();
     }
-    std::vector<std::string> ctg_ids = find(valid);
-    std::vector<std::string> opart(T);
+    std::vector<uint32_t> grp(nq), qs(nq), qe(nq);
+    run_shares(T, [&](uint32_t t) {
+        const Share &m = sh[t];
+        std::copy(m.grp.begin(), m.grp.end(), grp.begin() + m.first);
+        std::copy(m.qs.begin(), m.qs.end(), qs.begin() + m.first);
+        std::copy(m.qe.begin(), m.qe.end(), qe.begin() + m.first);
+    });
+    std::vector<int64_t> hit(nq ? nq : 1);
+    check(h_, gams_gpu_locate(h_, ctg_ix_, grp.data(), qs.data(), qe.data(), nq, hit.data()));
     auto join = [&] {
         std::string out;
         size_t bytes = 0;
-        for (auto &x : opart) bytes += x.size();
+        for (auto &m : sh) bytes += m.out.size();
         out.reserve(bytes);
-        for (auto &x : opart) out += x;
+        for (auto &m : sh) out += m.out;
         return out;
     };
     if (!is_count) {
         run_shares(T, [&](uint32_t t) {
-            std::string &o = opart[t];
-            for (size_t k = cut(valid.size(), t); k < cut(valid.size(), t + 1); ++k) {
-                if (ctg_ids[k].empty()) continue;                       // locate.rs:120-122
-                o += rgs[src[k]];
-                o += '\t';
-                o += ctg_ids[k];                                        // locate.rs:139
-                o += '\n';
+            Share &m = sh[t];
+            for (size_t j = 0; j < m.src.size(); ++j) {
+                const int64_t c = hit[m.first + j];
+                if (c < 0) continue;                                            // locate.rs:120-122
+                m.out += rgs[m.src[j]];
+                m.out += '\t';
+                m.out += ctgs_[(size_t)c].id;                                   // locate.rs:139
+                m.out += '\n';
             }
         });
         return join();
     }
     if (!rg_ix_) throw Error(GAMS_ESTATE, "locate --count: no rg index loaded");
-    std::vector<uint32_t> grp, qs, qe;
-    std::vector<size_t> who;
-    for (size_t k = 0; k < valid.size(); ++k) {
-        if (ctg_ids[k].empty()) continue;
-        auto it = rg_group_.find(ctg_ids[k]);
-        if (it == rg_group_.end()) fprintf(stderr, "%s not found in idx\n", ctg_ids[k].c_str());  // utils.rs:30
-        grp.push_back(it == rg_group_.end() ? UINT32_MAX : it->second);
-        qs.push_back((uint32_t)valid[k].start);
-        qe.push_back((uint32_t)valid[k].end);
-        who.push_back(k);
+    // rg group of every ctg of the table (UINT32_MAX: the ctg has no entry in the index)
+    std::vector<uint32_t> group_of(ctgs_.size(), UINT32_MAX);
+    for (size_t c = 0; c < ctgs_.size(); ++c) {
+        auto it = rg_group_.find(ctgs_[c].id);
+        if (it != rg_group_.end()) group_of[c] = it->second;
     }
-    std::vector<int32_t> cnt(who.size() ? who.size() : 1);
-    check(h_, gams_gpu_count(h_, rg_ix_, grp.data(), qs.data(), qe.data(), who.size(), cnt.data()));
+    // the located ranges, in line order: the reference counts only those (locate.rs:120-122, :135-137)
+    std::vector<size_t> kept(T + 1, 0);
+    for (unsigned t = 0; t < T; ++t) {
+        size_t n = 0;
+        for (size_t j = 0; j < sh[t].src.size(); ++j) n += hit[sh[t].first + j] >= 0;
+        kept[t + 1] = kept[t] + n;
+    }
+    const size_t nk = kept[T];
+    std::vector<uint32_t> cg(nk), cs(nk), ce(nk);
     run_shares(T, [&](uint32_t t) {
-        std::string &o = opart[t];
-        for (size_t j = cut(who.size(), t); j < cut(who.size(), t + 1); ++j) {
-            o += rgs[src[who[j]]];
-            o += '\t';
-            o += std::to_string(cnt[j]);                                // locate.rs:137
-            o += '\n';
+        const Share &m = sh[t];
+        size_t o = kept[t];
+        for (size_t j = 0; j < m.src.size(); ++j) {
+            const int64_t c = hit[m.first + j];
+            if (c < 0) continue;
+            cg[o] = group_of[(size_t)c];
+            cs[o] = qs[m.first + j];
+            ce[o] = qe[m.first + j];
+            ++o;
+        }
+    });
+    for (size_t o = 0; o < nk; ++o)                                             // utils.rs:30 (rare: serial is fine)
+        if (cg[o] == UINT32_MAX) {
+            // (which ctg: recomputed only on this path)
+            size_t seen = 0;
+            for (unsigned t = 0; t < T && seen <= o; ++t)
+                for (size_t j = 0; j < sh[t].src.size(); ++j) {
+                    const int64_t c = hit[sh[t].first + j];
+                    if (c < 0) continue;
+                    if (seen++ == o) fprintf(stderr, "%s not found in idx\n", ctgs_[(size_t)c].id.c_str());
+                }
+        }
+    std::vector<int32_t> cnt(nk ? nk : 1);
+    check(h_, gams_gpu_count(h_, rg_ix_, cg.data(), cs.data(), ce.data(), nk, cnt.data()));
+    run_shares(T, [&](uint32_t t) {
+        Share &m = sh[t];
+        size_t o = kept[t];
+        char num[16];
+        for (size_t j = 0; j < m.src.size(); ++j) {
+            if (hit[m.first + j] < 0) continue;
+            m.out += rgs[m.src[j]];
+            m.out += '\t';
+            auto r = std::to_chars(num, num + sizeof num, cnt[o++]);                // locate.rs:137
+            m.out.append(num, r.ptr);
+            m.out += '\n';
         }
     });
     return join();
@@ -1756,7 +1813,7 @@ std::string anno(gams_gpu_t *h, const std::map<std::string, Runlist> &sets, cons
     };
     const size_t first = header ? 1 : 0;
     const size_t n_lines = lines.size() > first ? lines.size() - first : 0;
-    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>({8, std::thread::hardware_concurrency(), n_lines / 20000}));
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>({16, std::thread::hardware_concurrency(), n_lines / 20000}));
     std::vector<Part> part(T);
     run_shares(T, [&](uint32_t t) {
         Part &P = part[t];

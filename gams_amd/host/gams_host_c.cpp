@@ -314,6 +314,8 @@ char *gams_host_sw_multi_timed(gams_gpu_t *const *handles, uint32_t n_handles, u
 
 // locate.rs:111-141.  rgs: newline-separated ranges (first TSV column already cut).
 // rg_lines (for --count): newline-separated "ctg_id\trange" rows = the rg: records per ctg.
+static thread_local double g_operator_ms = 0.0;
+
 char *gams_host_locate(gams_gpu_t *h, uint32_t n, const char *const *ids, const char *const *chrs,
                        const int32_t *starts, const int32_t *ends, const char *rgs, int is_count,
                        const char *rg_lines) {
@@ -330,9 +332,18 @@ char *gams_host_locate(gams_gpu_t *h, uint32_t n, const char *const *ids, const 
             }
             loc.set_rg_index(rg_of);
         }
-        return loc.locate(split_lines(rgs), is_count != 0);
+        const std::vector<std::string> lines = split_lines(rgs);
+        const auto t0 = std::chrono::steady_clock::now();
+        std::string out = loc.locate(lines, is_count != 0);
+        g_operator_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return out;
     });
 }
+
+// milliseconds the last gams_host_locate / gams_host_anno of this thread spent inside the operator itself
+// (Locator::locate, gams::anno: parsing of the range strings, device lookups, row text) -- without this wrapper's
+// splitting of its arguments into lines and, for --count, the build of the rg index, which are the caller's
+double gams_host_last_operator_ms(void) { return g_operator_ms; }
 
 // locate --seq (locate.rs:124-134).  seq_lines: "ctg_id\tbases" rows.
 char *gams_host_locate_seq(gams_gpu_t *h, uint32_t n, const char *const *ids, const char *const *chrs,
@@ -479,8 +490,12 @@ char *gams_host_anno(gams_gpu_t *h, uint32_t n, const char *const *ids, const ch
                 rl.hi.push_back(hi);
             }
         }
-        return gams::anno(h, sets, make_ctgs(n, ids, chrs, starts, ends), split_lines(lines), header != 0,
-                          prefix ? prefix : "", idx_id, idx_range);
+        const std::vector<gams::Ctg> cv = make_ctgs(n, ids, chrs, starts, ends);
+        const std::vector<std::string> lv = split_lines(lines);
+        const auto t0 = std::chrono::steady_clock::now();
+        std::string out = gams::anno(h, sets, cv, lv, header != 0, prefix ? prefix : "", idx_id, idx_range);
+        g_operator_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return out;
     });
 }
 

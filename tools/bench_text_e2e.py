@@ -32,12 +32,12 @@ rgs = [f"{ctgs[p]['chr_id']}:{s}-{e}" for p, s, e in zip(pick, starts, ends)]
 t0 = time.perf_counter()
 out = host.locate(eng, ctgs, rgs)
 t1 = time.perf_counter()
-print(f"locate: {N} ranges -> {out.count(chr(10))} lines in {(t1 - t0) * 1e3:.0f} ms")
+print(f"locate: {N} ranges -> {out.count(chr(10))} lines in {(t1 - t0) * 1e3:.0f} ms (the operator under the binding: {host.last_operator_ms():.1f} ms)")
 recs = [(ctgs[p]["id"], r) for p, r in zip(pick[:300000], rgs[:300000])]
 t0 = time.perf_counter()
 out = host.locate(eng, ctgs, rgs, count=True, rg_records=recs)
 t1 = time.perf_counter()
-print(f"locate --count: {N} ranges against {len(recs)} stored rg -> {out.count(chr(10))} lines in {(t1 - t0) * 1e3:.0f} ms")
+print(f"locate --count: {N} ranges against {len(recs)} stored rg -> {out.count(chr(10))} lines in {(t1 - t0) * 1e3:.0f} ms (operator: {host.last_operator_ms():.1f} ms)")
 runlists = {}
 for k, ln in enumerate(synth.ATHA_LENGTHS):
     cuts = np.sort(rng.choice(np.arange(1, ln, 7), min(60000, ln // 28 * 2), replace=False))
@@ -46,4 +46,4 @@ lines = [f"rg:{ctgs[p]['id']}:{i}\t{r}" for i, (p, r) in enumerate(zip(pick, rgs
 t0 = time.perf_counter()
 out = host.anno(eng, ctgs, runlists, lines, header=False, idx_id=1, idx_range=2)
 t1 = time.perf_counter()
-print(f"anno: {N} lines against {sum(v.count(',') + 1 for v in runlists.values())} spans -> {out.count(chr(10))} lines in {(t1 - t0) * 1e3:.0f} ms")
+print(f"anno: {N} lines against {sum(v.count(',') + 1 for v in runlists.values())} spans -> {out.count(chr(10))} lines in {(t1 - t0) * 1e3:.0f} ms (operator: {host.last_operator_ms():.1f} ms)")
