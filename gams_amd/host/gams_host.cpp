@@ -5,6 +5,7 @@
 #include <atomic>
 #include <mutex>
 #include <charconv>
+#include <string_view>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -95,17 +96,24 @@ std::string runlist(int64_t s, int64_t e) {
 
 // intspan::Range::from_str: [name.]chr[(strand)]:start[-end]
 Range Range::from_str(const std::string &in) {
+    // (views into `in` until the end: the text paths call this once per line, 10^6-10^8 times)
     Range r;
-    std::string s = in;
-    while (!s.empty() && (s.back() == '\r' || s.back() == '\n' || s.back() == ' ')) s.pop_back();
-    size_t colon = s.rfind(':');
-    if (colon == std::string::npos || colon == 0 || colon + 1 >= s.size()) return r;
-    std::string head = s.substr(0, colon), tail = s.substr(colon + 1);
+    std::string_view s(in);
+    while (!s.empty() && (s.back() == '\r' || s.back() == '\n' || s.back() == ' ')) s.remove_suffix(1);
+    const size_t colon = s.rfind(':');
+    if (colon == std::string_view::npos || colon == 0 || colon + 1 >= s.size()) return r;
+    std::string_view head = s.substr(0, colon);
+    const std::string_view tail = s.substr(colon + 1);
+    auto number = [](std::string_view d) {             // <= 10 digits: no overflow of long long
+        long long v = 0;
+        for (char c : d) v = v * 10 + (c - '0');
+        return v;
+    };
     // start[-_]end
     size_t i = 0;
     while (i < tail.size() && tail[i] >= '0' && tail[i] <= '9') ++i;
     if (i == 0 || i > 10) return r;
-    long long st = std::atoll(tail.substr(0, i).c_str()), en = st;
+    long long st = number(tail.substr(0, i)), en = st;
     if (i < tail.size()) {
         size_t j = i;
         while (j < tail.size() && (tail[j] == '-' || tail[j] == '_')) ++j;
@@ -113,25 +121,28 @@ Range Range::from_str(const std::string &in) {
         size_t k = j;
         while (k < tail.size() && tail[k] >= '0' && tail[k] <= '9') ++k;
         if (k == j || k != tail.size() || k - j > 10) return r;
-        en = std::atoll(tail.substr(j, k - j).c_str());
+        en = number(tail.substr(j, k - j));
     }
     if (st > INT32_MAX || en > INT32_MAX) return r;
     // head: [name.]chr[(strand)]
+    std::string_view strand, name;
     if (!head.empty() && head.back() == ')') {
-        size_t open = head.rfind('(');
-        if (open == std::string::npos) return r;
-        r.strand = head.substr(open + 1, head.size() - open - 2);
+        const size_t open = head.rfind('(');
+        if (open == std::string_view::npos) return r;
+        strand = head.substr(open + 1, head.size() - open - 2);
         head = head.substr(0, open);
     }
-    size_t dot = head.find('.');
-    if (dot != std::string::npos) {
-        r.name = head.substr(0, dot);
+    const size_t dot = head.find('.');
+    if (dot != std::string_view::npos) {
+        name = head.substr(0, dot);
         head = head.substr(dot + 1);
     }
     if (head.empty()) return r;
     for (char c : head)
         if (!(is_word(c) || c == '-' || c == '/')) return r;
-    r.chr = head;
+    r.strand.assign(strand);
+    r.name.assign(name);
+    r.chr.assign(head);
     r.start = (int32_t)st;
     r.end = (int32_t)en;
     r.valid = true;
