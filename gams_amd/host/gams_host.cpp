@@ -1773,21 +1773,6 @@ bool extract_ctg_id(const std::string &s, std::string &id) {
     return false;
 }
 
-std::vector<std::string> split_tab(const std::string &s) {
-    std::vector<std::string> parts;
-    size_t b = 0;
-    for (;;) {
-        size_t e = s.find('\t', b);
-        if (e == std::string::npos) {
-            parts.push_back(s.substr(b));
-            break;
-        }
-        parts.push_back(s.substr(b, e - b));
-        b = e + 1;
-    }
-    return parts;
-}
-
 }  // namespace
 
 std::string anno(gams_gpu_t *h, const std::map<std::string, Runlist> &sets, const std::vector<Ctg> &ctgs,
@@ -1830,12 +1815,22 @@ std::string anno(gams_gpu_t *h, const std::map<std::string, Runlist> &sets, cons
         Part &P = part[t];
         const size_t b0 = first + n_lines * t / T, b1 = first + n_lines * (t + 1) / T;
         for (size_t i = b0; i < b1; ++i) {                             // anno.rs:97
-            std::vector<std::string> parts = split_tab(lines[i]);
-            if (idx_id == 0 || idx_range == 0 || idx_id > parts.size() || idx_range > parts.size())
+            // the two tab-separated fields the line is asked for (no vector of all its fields)
+            const std::string &ln = lines[i];
+            size_t n_fields = 0, fb = 0, id_b = 0, id_e = 0, rg_b = 0, rg_e = 0;
+            for (;;) {
+                const size_t fe = std::min(ln.find('\t', fb), ln.size());
+                ++n_fields;
+                if (n_fields == idx_id) id_b = fb, id_e = fe;
+                if (n_fields == idx_range) rg_b = fb, rg_e = fe;
+                if (fe == ln.size()) break;
+                fb = fe + 1;
+            }
+            if (idx_id == 0 || idx_range == 0 || idx_id > n_fields || idx_range > n_fields)
                 throw Error(GAMS_EINVAL, "anno: field index out of range (the reference panics, anno.rs:115)");
             std::string ctg_id;
-            if (!extract_ctg_id(parts[idx_id - 1], ctg_id)) continue;   // anno.rs:116-119
-            Range r = Range::from_str(parts[idx_range - 1]);
+            if (!extract_ctg_id(ln.substr(id_b, id_e - id_b), ctg_id)) continue;   // anno.rs:116-119
+            Range r = Range::from_str(ln.substr(rg_b, rg_e - rg_b));
             if (!r.valid) continue;                                     // anno.rs:123-125
             auto gi = group_of.find(r.chr);
             uint32_t gq = UINT32_MAX;
