@@ -72,6 +72,7 @@ PROTOTYPES = {
     "gams_wave_rows_setup": (C.c_int, [_VP, _VP, C.POINTER(C.c_char_p), _VP, C.c_float]),
     "gams_wave_rows_begin": (C.c_int, [_VP, _VP]),
     "gams_wave_rows_end": (C.c_int, [_VP, _VP, _PP, C.POINTER(C.c_uint64), _PP]),
+    "gams_wave_signal_text": (C.c_int, [_VP, _VP, C.POINTER(C.c_char_p), _VP, _PP, C.POINTER(C.c_uint64), _PP]),
     "gams_wave_dense": (C.c_int, [_VP, _VP, C.c_uint32, _VP, _VP]),
     "gams_wave_plan_set_tile": (C.c_int, [_VP, _VP, C.c_uint32]),
     "gams_wave_plan_set_threads": (C.c_int, [_VP, _VP, C.c_uint32]),

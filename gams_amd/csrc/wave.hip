@@ -86,6 +86,24 @@ struct WaveRows {
     bool begun = false;
 };
 
+// gams_wave_signal_text: the `--signal` rows of a pass as text (wave_rows.hpp, sig_*_kernel)
+struct WaveSig {
+    uint8_t *arena = nullptr;                 // SigTile[nt] | blk_len[nt] | blk_off[nt + 2] | RowCtg[n_ctg] | names | gc table | words[n_ctg]
+    size_t arena_bytes = 0;
+    uint32_t n_tiles = 0;
+    SigTile *d_tiles = nullptr;
+    uint32_t *d_blk_len = nullptr;
+    unsigned long long *d_blk_off = nullptr, *d_words = nullptr;
+    RowCtg *d_ctgs = nullptr;
+    char *d_names = nullptr;
+    uint8_t *d_gctab = nullptr;
+    size_t names_cap = 0;
+    char *d_text = nullptr, *h_text = nullptr;      // h_text: page-locked
+    size_t d_text_bytes = 0, h_text_bytes = 0;
+    unsigned long long *h_words = nullptr;          // page-locked: words[n_ctg], then ctg_off[n_ctg + 1] made on the host
+    size_t h_words_bytes = 0;
+};
+
 struct Launcher;
 struct gams_wave_plan {
     gams_seqset_t *set = nullptr;
@@ -173,6 +191,7 @@ struct gams_wave_plan {
     float g0 = 0, g1 = 0, g2 = 0, g3 = 0;
     float sq[6] = {0, 0, 0, 0, 0, 0};   // aA, aB, gA0, gA1, gB0, gB1 (wave_squared_band)
     WaveRows *rows = nullptr;           // gams_wave_rows_setup
+    WaveSig *sigtext = nullptr;         // gams_wave_signal_text
     float guard_safety = 1.5f;          // gams_wave_plan_set_guard
     bool guard_exact = false;           // every window through the exact path
 };
@@ -748,6 +767,15 @@ void gams_wave_plan_destroy(gams_gpu_t *h, gams_wave_plan_t *p) {
             if (g.exec) (void)hipGraphExecDestroy(g.exec);
         delete r;
         p->rows = nullptr;
+    }
+    if (p->sigtext) {
+        WaveSig *g = p->sigtext;
+        gams_pool_free(h, false, g->arena, g->arena_bytes);
+        gams_pool_free(h, false, g->d_text, g->d_text_bytes);
+        gams_pool_free(h, true, g->h_text, g->h_text_bytes);
+        gams_pool_free(h, true, g->h_words, g->h_words_bytes);
+        delete g;
+        p->sigtext = nullptr;
     }
     gams_pool_free(h, false, p->arena_fixed, p->arena_fixed_bytes);
     gams_pool_free(h, false, p->arena_geom, p->arena_geom_bytes);
@@ -1933,6 +1961,143 @@ int gams_wave_rows_end(gams_gpu_t *h, gams_wave_plan_t *p, const char **text, ui
         if (rc != GAMS_OK) return rc;
     }
     return gams_fail(h, GAMS_EHIP, "wave_rows: buffers kept overflowing");
+}
+
+int gams_wave_signal_text(gams_gpu_t *h, gams_wave_plan_t *p, const char *const *chr, const int32_t *chr_start,
+                          const char **text, uint64_t *text_bytes, const uint64_t **ctg_off) {
+    if (!h || !p || !text || !text_bytes || !ctg_off || (p->set->n_ctg && (!chr || !chr_start)))
+        return gams_fail(h, GAMS_EINVAL, "wave_signal_text: null argument");
+    if (!(p->flags & GAMS_WAVE_DENSE)) return gams_fail(h, GAMS_ESTATE, "wave_signal_text: plan has no DENSE output");
+    if (!p->ran) return gams_fail(h, GAMS_ESTATE, "wave_signal_text: no run to read");
+    const gams_wave_params_t &q = p->prm;
+    const uint32_t n_ctg = p->set->n_ctg;
+    for (uint32_t c = 0; c < n_ctg; ++c) {
+        if (!chr[c]) return gams_fail(h, GAMS_EINVAL, "wave_signal_text: null chromosome name");
+        if (chr_start[c] < 0 || (int64_t)chr_start[c] + p->ctgs[c].len >= 0x7FFFFFFFll)
+            return gams_fail(h, GAMS_EINVAL, "wave_signal_text: chromosome coordinates must be in [0, 2^31)");
+    }
+    GAMS_HIP(h, hipSetDevice(h->device));
+    {
+        int wrc = wave_jac_settle(h, p, wave_read_way_index(p));
+        if (wrc == GAMS_OK) wrc = wave_wait_last_run(h, p);
+        if (wrc != GAMS_OK) return wrc;
+    }
+    // names, gc text table (as gams_wave_rows_setup), tiles of kSigRows windows
+    std::vector<RowCtg> rc(std::max<uint32_t>(n_ctg, 1));
+    std::string blob;
+    for (uint32_t c = 0; c < n_ctg; ++c) {
+        const size_t len = std::strlen(chr[c]);
+        size_t at = blob.find(chr[c]);
+        if (at == std::string::npos || len == 0) {
+            at = blob.size();
+            blob += chr[c];
+        }
+        rc[c] = RowCtg{(uint32_t)at, (uint32_t)len, chr_start[c], 0u};
+    }
+    std::vector<uint8_t> gct(((size_t)q.size + 1) * kGcStride, 0);
+    for (int32_t k = 0; k <= q.size; ++k) {
+        const std::string t = rows_fmt_f32((float)k / (float)q.size);
+        if (t.size() > kGcStride - 1) return gams_fail(h, GAMS_EUNSUPPORTED, "wave_signal_text: gc_content text too long");
+        gct[(size_t)k * kGcStride] = (uint8_t)t.size();
+        std::memcpy(&gct[(size_t)k * kGcStride + 1], t.data(), t.size());
+    }
+    if (!p->sigtext) p->sigtext = new WaveSig();
+    WaveSig *g = p->sigtext;
+    if (!g->arena || g->names_cap < blob.size()) {
+        gams_pool_free(h, false, g->arena, g->arena_bytes);
+        g->arena = nullptr;
+        std::vector<SigTile> st;
+        for (uint32_t c = 0; c < n_ctg; ++c)
+            for (uint32_t w0 = 0; w0 < p->ctgs[c].n_win; w0 += kSigRows)
+                st.push_back(SigTile{c, w0, p->ctgs[c].n_win, 0u, p->ctgs[c].win_base});
+        g->n_tiles = (uint32_t)st.size();
+        g->names_cap = std::max<size_t>(blob.size(), 64) * 2;
+        const size_t nt = std::max<size_t>(st.size(), 1);
+        const size_t b_tiles = wave_align256(nt * sizeof(SigTile)), b_len = wave_align256(nt * 4), b_off = wave_align256((nt + 2) * 8),
+                     b_ctgs = wave_align256(rc.size() * sizeof(RowCtg)), b_names = wave_align256(g->names_cap),
+                     b_gc = wave_align256(gct.size()), b_words = wave_align256(std::max<size_t>(n_ctg, 1) * 8);
+        GAMS_HIP(h, gams_pool_alloc(h, false, b_tiles + b_len + b_off + b_ctgs + b_names + b_gc + b_words,
+                                    reinterpret_cast<void **>(&g->arena), &g->arena_bytes));
+        uint8_t *o = g->arena;
+        g->d_tiles = reinterpret_cast<SigTile *>(o), o += b_tiles;
+        g->d_blk_len = reinterpret_cast<uint32_t *>(o), o += b_len;
+        g->d_blk_off = reinterpret_cast<unsigned long long *>(o), o += b_off;
+        g->d_ctgs = reinterpret_cast<RowCtg *>(o), o += b_ctgs;
+        g->d_names = reinterpret_cast<char *>(o), o += b_names;
+        g->d_gctab = o, o += b_gc;
+        g->d_words = reinterpret_cast<unsigned long long *>(o);
+        if (!st.empty()) GAMS_HIP(h, hipMemcpy(g->d_tiles, st.data(), st.size() * sizeof(SigTile), hipMemcpyHostToDevice));
+        gams_pool_free(h, true, g->h_words, g->h_words_bytes);
+        g->h_words = nullptr;
+        GAMS_HIP(h, gams_pool_alloc(h, true, ((size_t)2 * n_ctg + 2) * 8, reinterpret_cast<void **>(&g->h_words), &g->h_words_bytes));
+    }
+    *text = nullptr;
+    *text_bytes = 0;
+    unsigned long long *off = g->h_words + n_ctg;          // ctg_off[n_ctg + 1]
+    if (g->n_tiles == 0) {
+        for (uint32_t c = 0; c <= n_ctg; ++c) off[c] = 0;
+        *ctg_off = reinterpret_cast<const uint64_t *>(off);
+        return GAMS_OK;
+    }
+    hipStream_t st = h->readback;
+    GAMS_HIP(h, hipMemcpyAsync(g->d_ctgs, rc.data(), rc.size() * sizeof(RowCtg), hipMemcpyHostToDevice, st));
+    if (!blob.empty()) GAMS_HIP(h, hipMemcpyAsync(g->d_names, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
+    GAMS_HIP(h, hipMemcpyAsync(g->d_gctab, gct.data(), gct.size(), hipMemcpyHostToDevice, st));
+    GAMS_HIP(h, hipMemsetAsync(g->d_words, 0xFF, std::max<size_t>(n_ctg, 1) * 8, st));
+    gams_wave_plan::Way &w = wave_read_way(p);
+    SigArgs a{};
+    a.tiles = g->d_tiles;
+    a.n_tiles = g->n_tiles;
+    a.cnt = w.d_dense_cnt;
+    a.sig = w.d_dense_sig;
+    a.ctgs = g->d_ctgs;
+    a.names = g->d_names;
+    a.gctab = g->d_gctab;
+    a.size = (uint32_t)q.size;
+    a.step = (uint32_t)q.step;
+    a.blk_len = g->d_blk_len;
+    a.blk_off = g->d_blk_off;
+    a.words = g->d_words;
+    hipLaunchKernelGGL(sig_len_kernel, dim3(g->n_tiles), dim3(256), 0, st, a);
+    unsigned long long *const d_totals = g->d_blk_off + g->n_tiles;
+    if (g->n_tiles <= kOffOneGroup) {
+        hipLaunchKernelGGL(wave_offsets_kernel, dim3(1), dim3(1024), 0, st, g->d_blk_len, g->n_tiles, g->d_blk_off, d_totals);
+    } else {
+        const unsigned spans = (g->n_tiles + kOffSpan - 1u) / kOffSpan;
+        hipLaunchKernelGGL(wave_offsets_sum_kernel, dim3(spans), dim3(1024), 0, st, g->d_blk_len, g->n_tiles, g->d_blk_off);
+        hipLaunchKernelGGL(wave_offsets_base_kernel, dim3(1), dim3(1024), 0, st, g->n_tiles, g->d_blk_off, d_totals);
+        hipLaunchKernelGGL(wave_offsets_scan_kernel, dim3(spans), dim3(1024), 0, st, g->d_blk_len, g->n_tiles, g->d_blk_off);
+    }
+    GAMS_HIP(h, hipGetLastError());
+    GAMS_HIP(h, hipMemcpyAsync(h->pin_scratch, d_totals, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    GAMS_HIP(h, hipStreamSynchronize(st));       // (the staged tables above live on this call's stack until here)
+    const uint64_t total = h->pin_scratch[0];
+    if (total > g->d_text_bytes) {
+        gams_pool_free(h, false, g->d_text, g->d_text_bytes);
+        g->d_text = nullptr;
+        g->d_text_bytes = 0;
+        GAMS_HIP(h, gams_pool_alloc(h, false, total + total / 16 + 4096, reinterpret_cast<void **>(&g->d_text), &g->d_text_bytes));
+    }
+    if (total > g->h_text_bytes) {
+        gams_pool_free(h, true, g->h_text, g->h_text_bytes);
+        g->h_text = nullptr;
+        g->h_text_bytes = 0;
+        GAMS_HIP(h, gams_pool_alloc(h, true, total + total / 16 + 4096, reinterpret_cast<void **>(&g->h_text), &g->h_text_bytes));
+    }
+    a.text = g->d_text;
+    a.text_cap = total;
+    hipLaunchKernelGGL(sig_write_kernel, dim3(g->n_tiles), dim3(256), 0, st, a);
+    GAMS_HIP(h, hipGetLastError());
+    GAMS_HIP(h, hipMemcpyAsync(g->h_words, g->d_words, std::max<size_t>(n_ctg, 1) * 8, hipMemcpyDeviceToHost, st));
+    if (total) GAMS_HIP(h, hipMemcpyAsync(g->h_text, g->d_text, total, hipMemcpyDeviceToHost, st));
+    GAMS_HIP(h, hipStreamSynchronize(st));
+    // where each ctg's rows begin: ctgs without a window begin where the next one does
+    off[n_ctg] = total;
+    for (uint32_t c = n_ctg; c-- > 0;) off[c] = p->ctgs[c].n_win ? g->h_words[c] : off[c + 1];
+    *text = g->h_text;
+    *text_bytes = total;
+    *ctg_off = reinterpret_cast<const uint64_t *>(off);
+    return GAMS_OK;
 }
 
 int gams_wave_dense(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t i, uint32_t *gc_count, int8_t *signal) {

@@ -341,4 +341,110 @@ __global__ __launch_bounds__(256) void rows_write_kernel(const RowArgs a) {
     if (tid < tot - done) dst[done + tid] = stage[mis + done + tid];
 }
 
+// ---- `wave --signal`: a row for EVERY window (wave.rs:158-168) ----------------------------------------------------
+// "{chr}:{start}-{end}\t{gc_content}\t{signal}\n" from the dense rows of the pass (count, signal per window): a
+// workgroup takes 256 consecutive windows of one ctg (SigTile), sig_len_kernel sums the row lengths per tile,
+// wave_offsets_* turns them into the tiles' offsets in the text, sig_write_kernel builds a tile's text in LDS and stores
+// it in 16-B units like rows_write_kernel.  120 Mb at step 10: 1.2e7 rows, 310 MB of text.
+constexpr uint32_t kSigRows = 256;
+
+struct SigTile {
+    uint32_t ctg, w0;          // first window of the tile
+    uint32_t n_win;            // windows of the ctg
+    uint32_t pad;
+    uint64_t win_base;         // the ctg's first row in the dense arrays
+};
+
+struct SigArgs {
+    const SigTile *tiles;
+    uint32_t n_tiles;
+    const uint32_t *cnt;
+    const int8_t *sig;
+    const RowCtg *ctgs;
+    const char *names;
+    const uint8_t *gctab;                    // [size + 1][kGcStride]
+    uint32_t size, step;
+    uint32_t *blk_len;                       // per tile: bytes of its rows
+    const unsigned long long *blk_off;       // per tile: where they begin
+    char *text;
+    uint64_t text_cap;
+    unsigned long long *words;               // per ctg: where its rows begin (ctgs without a window keep ~0)
+};
+
+__device__ __forceinline__ uint32_t sig_row_len(const SigArgs &a, const RowCtg cg, uint32_t i, uint32_t k, int sg) {
+    const uint32_t s = (uint32_t)cg.chr_start + i * a.step, e = s + a.size - 1u;
+    return cg.name_len + 1u + dec_digits(s) + (e != s ? 1u + dec_digits(e) : 0u) + 1u + a.gctab[(size_t)k * kGcStride] + 1u +
+           (sg < 0 ? 2u : 1u) + 1u;
+}
+
+__global__ __launch_bounds__(256) void sig_len_kernel(const SigArgs a) {
+    __shared__ uint32_t ws[4];
+    const SigTile t = a.tiles[blockIdx.x];
+    const uint32_t tid = threadIdx.x, i = t.w0 + tid;
+    uint32_t len = 0;
+    if (i < t.n_win) len = sig_row_len(a, a.ctgs[t.ctg], i, a.cnt[t.win_base + i], a.sig[t.win_base + i]);
+    for (int d = 32; d; d >>= 1) len += (uint32_t)__shfl_xor((int)len, d, 64);
+    if ((tid & 63u) == 0u) ws[tid >> 6] = len;
+    __syncthreads();
+    if (tid == 0u) a.blk_len[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__device__ __forceinline__ void sig_row_put(const SigArgs &a, char *p, const RowCtg cg, uint32_t i, uint32_t k, int sg) {
+    const uint32_t s = (uint32_t)cg.chr_start + i * a.step, e = s + a.size - 1u;
+    for (uint32_t q = 0; q < cg.name_len; ++q) *p++ = a.names[cg.name_off + q];
+    *p++ = ':';
+    p += dec_digits(s);
+    put_dec_back(p, s);
+    if (e != s) {                                   // IntSpan::runlist of a single position is that position
+        *p++ = '-';
+        p += dec_digits(e);
+        put_dec_back(p, e);
+    }
+    *p++ = '\t';
+    const uint8_t *g = a.gctab + (size_t)k * kGcStride;
+    for (uint32_t q = 0; q < g[0]; ++q) *p++ = (char)g[1u + q];
+    *p++ = '\t';
+    if (sg < 0) *p++ = '-';
+    *p++ = sg == 0 ? '0' : '1';
+    *p++ = '\n';
+}
+
+__global__ __launch_bounds__(256) void sig_write_kernel(const SigArgs a) {
+    __shared__ uint32_t scr[4];
+    __shared__ __align__(16) char stage[kRowsStage + 16];
+    const SigTile t = a.tiles[blockIdx.x];
+    const uint32_t tid = threadIdx.x, i = t.w0 + tid;
+    const RowCtg cg = a.ctgs[t.ctg];
+    uint32_t k = 0, len = 0;
+    int sg = 0;
+    if (i < t.n_win) {
+        k = a.cnt[t.win_base + i];
+        sg = a.sig[t.win_base + i];
+        len = sig_row_len(a, cg, i, k, sg);
+    }
+    uint32_t tot;
+    const uint32_t rel = block_excl_scan_256<uint32_t>(len, scr, tot);
+    const uint64_t blk0 = a.blk_off[blockIdx.x];
+    if (t.w0 == 0u && tid == 0u) a.words[t.ctg] = blk0;
+    const uint32_t mis = (uint32_t)(blk0 & 15u);
+    const bool staged = tot <= kRowsStage && blk0 + tot <= a.text_cap;
+    if (len) {
+        if (staged)
+            sig_row_put(a, stage + mis + rel, cg, i, k, sg);
+        else if (blk0 + rel + len <= a.text_cap)
+            sig_row_put(a, a.text + blk0 + rel, cg, i, k, sg);
+    }
+    if (!staged) return;
+    __syncthreads();
+    const uint32_t head = min(tot, (16u - mis) & 15u);
+    char *const dst = a.text + blk0;
+    if (tid < head) dst[tid] = stage[mis + tid];
+    const uint32_t units = (tot - head) >> 4;
+    const uint4 *const su = reinterpret_cast<const uint4 *>(stage + mis + head);
+    uint4 *const du = reinterpret_cast<uint4 *>(dst + head);
+    for (uint32_t q = tid; q < units; q += 256u) du[q] = su[q];
+    const uint32_t done = head + (units << 4);
+    if (tid < tot - done) dst[done + tid] = stage[mis + done + tid];
+}
+
 }  // namespace

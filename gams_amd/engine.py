@@ -186,6 +186,19 @@ class WavePlan:
         offs = np.frombuffer((C.c_uint64 * (n_ctg + 1)).from_address(off.value), np.uint64).copy()
         return (C.string_at(txt.value, n.value) if n.value else b""), offs
 
+    def signal_text(self, chr_names, chr_starts, copy=True):
+        """`wave --signal` rows of the selected run as text from the device -> (text bytes, ctg offsets) (copy=False: byte count)"""
+        n = len(chr_names)
+        names = (C.c_char_p * max(n, 1))(*[x.encode() for x in chr_names])
+        starts = np.asarray(chr_starts, np.int32)
+        txt, nb, off = C.c_void_p(), C.c_uint64(), C.c_void_p()
+        self.eng.check(self.eng.lib.gams_wave_signal_text(self.eng.h, self.p, names, starts.ctypes.data, C.byref(txt), C.byref(nb),
+                                                          C.byref(off)))
+        if not copy:
+            return int(nb.value)
+        offs = np.frombuffer((C.c_uint64 * (n + 1)).from_address(off.value), np.uint64).copy()
+        return (C.string_at(txt.value, nb.value) if nb.value else b""), offs
+
     def set_taper_shape(self, pct4, pct8=None):
         """size of the tapered launch's two tails in % of a round of workgroup slots (default 25 / 50)"""
         if pct8 is None:                      # tools/ab_plans.py passes one integer: pct4 * 1000 + pct8

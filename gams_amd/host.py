@@ -165,7 +165,7 @@ def _stage_dict(st):
     return d
 
 
-def wave_timed(eng, ctgs, size=100, step=10, lag=100, threshold=3.0, influence=1.0, coverage=0.2, sync=False):
+def wave_timed(eng, ctgs, size=100, step=10, lag=100, threshold=3.0, influence=1.0, coverage=0.2, sync=False, is_signal=False):
     """`wave` from gunzipped host buffers -> (TSV bytes, stage clock dict of gams::WaveStages)."""
     n, ids, chrs, st, en = _ctg_arrays(ctgs)
     bufs = [np.ascontiguousarray(np.frombuffer(c["seq"], np.uint8) if not isinstance(c["seq"], np.ndarray)
@@ -174,7 +174,7 @@ def wave_timed(eng, ctgs, size=100, step=10, lag=100, threshold=3.0, influence=1
     stages = (C.c_double * 10)()
     ln = C.c_uint64()
     p = load().gams_host_wave_timed(eng.h, n, ids, chrs, st.ctypes.data, en.ctypes.data, seqs, size, step, lag,
-                                    threshold, influence, coverage, int(sync), stages, C.byref(ln))
+                                    threshold, influence, coverage, int(sync) | (2 if is_signal else 0), stages, C.byref(ln))
     return _take_bytes(p, ln), _stage_dict(stages)
 
 

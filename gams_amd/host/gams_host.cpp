@@ -425,6 +425,43 @@ std::vector<std::string> WaveJob::finish() {
     if (n == 0) return out;
     const float fsize = (float)a.size;
     if (a.signal) {                                                     // wave.rs:158-168
+        // the rows as text from the device (gams_wave_signal_text); what it does not cover goes the host way below
+        {
+            std::vector<const char *> chr(n);
+            std::vector<int32_t> cst(n);
+            for (uint32_t c = 0; c < n; ++c) {
+                chr[c] = ctgs[c].chr_id.c_str();
+                cst[c] = ctgs[c].chr_start;
+            }
+            const char *text = nullptr;
+            uint64_t bytes = 0;
+            const uint64_t *off = nullptr;
+            const int rc = gams_wave_signal_text(h, pg.p, chr.data(), cst.data(), &text, &bytes, &off);
+            if (rc == GAMS_OK) {
+                mark(&WaveStages::peaks_ms);
+                const unsigned T = (unsigned)std::max<uint64_t>(
+                    1, std::min<uint64_t>({16, std::thread::hardware_concurrency(), (uint64_t)n, bytes / (4u << 20) + 1}));
+                std::atomic<uint32_t> next{0};
+                std::vector<std::exception_ptr> errs(T);
+                auto work = [&](unsigned t) {
+                    try {
+                        for (uint32_t c = next.fetch_add(1); c < n; c = next.fetch_add(1)) out[c].assign(text + off[c], text + off[c + 1]);
+                    } catch (...) {
+                        errs[t] = std::current_exception();
+                    }
+                };
+                std::vector<std::thread> pool;
+                for (unsigned t = 1; t < T; ++t) pool.emplace_back(work, t);
+                work(0);
+                for (auto &th : pool) th.join();
+                for (auto &er : errs)
+                    if (er) std::rethrow_exception(er);
+                if (st) st->peaks = bytes;
+                mark(&WaveStages::format_ms);
+                return out;
+            }
+            if (rc != GAMS_EUNSUPPORTED && rc != GAMS_EINVAL) check(h, rc);
+        }
         // fetch the dense rows on this thread (the handle's), format the ctgs on several
         std::vector<std::vector<uint32_t>> cnts(n);
         std::vector<std::vector<int8_t>> sigs(n);

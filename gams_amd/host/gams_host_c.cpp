@@ -126,8 +126,8 @@ void put_stages(const gams::WaveStages &st, double *stages) {
 }
 }  // namespace
 
-// gams_host_wave with the stage clock of gams::WaveStages (sync != 0: the device is drained at every stage
-// boundary); *out_len receives the length of the text
+// gams_host_wave with the stage clock of gams::WaveStages (sync bit 0: the device is drained at every stage
+// boundary; bit 1: `--signal`, a row for every window); *out_len receives the length of the text
 char *gams_host_wave_timed(gams_gpu_t *h, uint32_t n, const char *const *ids, const char *const *chrs,
                            const int32_t *starts, const int32_t *ends, const uint8_t *const *seqs, int32_t size,
                            int32_t step, uint32_t lag, float threshold, float influence, float coverage, int sync,
@@ -140,8 +140,9 @@ char *gams_host_wave_timed(gams_gpu_t *h, uint32_t n, const char *const *ids, co
         a.threshold = threshold;
         a.influence = influence;
         a.coverage = coverage;
+        a.signal = (sync & 2) != 0;
         gams::WaveStages st;
-        st.sync = sync != 0;
+        st.sync = (sync & 1) != 0;
         std::vector<const uint8_t *> sp(seqs, seqs + n);
         std::vector<std::string> rows = gams::wave_proc_ctgs(h, make_ctgs(n, ids, chrs, starts, ends), sp, a, &st);
         put_stages(st, stages);

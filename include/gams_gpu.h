@@ -177,6 +177,13 @@ int gams_wave_rows_setup(gams_gpu_t *h, gams_wave_plan_t *p, const char *const *
 int gams_wave_rows_begin(gams_gpu_t *h, gams_wave_plan_t *p);
 int gams_wave_rows_end(gams_gpu_t *h, gams_wave_plan_t *p, const char **text, uint64_t *text_bytes,
                        const uint64_t **ctg_off);
+/* `wave --signal` (wave.rs:158-168: a row for EVERY window, "{chr}:{start}-{end}\t{gc_content}\t{signal}\n") as text made
+ * on the device from the dense rows of the selected run of a plan with GAMS_WAVE_DENSE.  chr[i] / chr_start[i] as in
+ * gams_wave_rows_setup.  Waits for the run; *text (text_bytes bytes, no header line, no NUL) and *ctg_off (n_ctg + 1
+ * offsets: the rows of ctg i are text[ctg_off[i] .. ctg_off[i+1])) point into plan-owned page-locked memory, valid
+ * until the next call on this plan.  120 Mb at step 10 are 1.2e7 rows and 310 MB of text. */
+int gams_wave_signal_text(gams_gpu_t *h, gams_wave_plan_t *p, const char *const *chr, const int32_t *chr_start,
+                          const char **text, uint64_t *text_bytes, const uint64_t **ctg_off);
 /* Wait for the last run and copy ctg i's dense rows (either pointer may be NULL). */
 int gams_wave_dense(gams_gpu_t *h, gams_wave_plan_t *p, uint32_t i,
                     uint32_t *gc_count, int8_t *signal);

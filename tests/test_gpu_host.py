@@ -671,6 +671,33 @@ def test_device_rows_over_tiles_of_one_wave(eng):
     ss.close()
 
 
+@pytest.mark.parametrize("prm", [dict(), dict(size=100, step=1, lag=100), dict(size=1, step=1, lag=50, threshold=2.0),
+                                 dict(size=50, step=7, lag=33, threshold=2.5), dict(size=300, step=10, lag=250),
+                                 dict(influence=0.5), dict(influence=0.0, threshold=2.0), dict(size=100, step=150, lag=20)])
+def test_signal_text_from_the_device_equals_the_oracle(eng, s288c, prm):
+    """gams_wave_signal_text: `wave --signal` rows (one per window, wave.rs:158-168) as text made on the device -- against
+    the oracle's text per ctg, with ragged ctgs, names of several lengths, large coordinates, a ctg without any signal,
+    single-base windows (the runlist of one position has no dash); then the same through the host operator."""
+    quiet = dict(id="ctg:quiet:1", chr_id="quiet", chr_start=5, chr_end=5 + 4000 - 1, seq=b"ACGT" * 1000)
+    ctgs = (all_ctgs(s288c, piece=30000)[:4] + [quiet] + all_ctgs(s288c, piece=30000)[4:7]
+            + [dict(id="ctg:a-long_name.7:1", chr_id="a-long_name.7", chr_start=1_999_000_001, chr_end=1_999_000_001 + 25000 - 1,
+                    seq=bytes(s288c["Mito"][:25000]))])
+    kw = dict(size=100, step=10, lag=100, threshold=3.0, influence=1.0)
+    kw.update(prm)
+    ss = engine.SeqSet(eng, [c["seq"] for c in ctgs])
+    plan = engine.WavePlan(eng, ss, kw["size"], kw["step"], kw["lag"], kw["threshold"], kw["influence"], flags=_lib.WAVE_DENSE)
+    for rep in range(2):                       # (the second call reuses the plan's tables and text buffers)
+        plan.run()
+        text, off = plan.signal_text([c["chr_id"] for c in ctgs], [c["chr_start"] for c in ctgs])
+    assert int(off[0]) == 0 and int(off[-1]) == len(text)
+    for c, ctg in enumerate(ctgs):
+        exp = ora.wave_proc_ctg(ctg["chr_id"], ctg["chr_start"], ctg["chr_end"], ctg["seq"], is_signal=True, **kw)
+        assert text[int(off[c]):int(off[c + 1])].decode() == exp, (prm, c)
+    plan.close()
+    ss.close()
+    assert host.wave(eng, ctgs, is_signal=True, **kw) == text.decode()
+
+
 def test_device_rows_of_several_plans_in_flight(eng, s288c):
     """rows_begin of three plans on three lanes before the first rows_end: every plan gets its own text."""
     batches = [all_ctgs(s288c, piece=40000)[k::3] for k in range(3)]
