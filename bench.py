@@ -611,7 +611,10 @@ def main():
                                                       f"worker thread, {T} threads on {os.cpu_count()} cpus"}
             out["parity_vs_oracle"] = ok
         if world == 1 and not args.no_e2e:
-            out["end_to_end"] = end_to_end(eng, batches[0], prm)
+            try:                                    # (an optional block must not take the line with it)
+                out["end_to_end"] = end_to_end(eng, batches[0], prm)
+            except Exception as e:  # noqa: BLE001
+                out["end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
     for p in plans:
         p.close()
     for ss in sets:
@@ -621,85 +624,91 @@ def main():
         from gams_amd import synth
 
         extra = {}
-        # (a) BASELINE configs[1]: the 12-Mb genome lives in L2/MALL and one launch lasts microseconds
-        #     (launch-latency bound); (b) a 384-Mb genome, one launch beyond the Infinity Cache.
-        for tag, lengths, piece, depth in (("S288c", synth.S288C_LENGTHS, 500000, 4),
-                                           ("synth384", synth.SYNTH384_LENGTHS, 1000000, 1)):
-            if tag == args.workload:
-                continue
-            g = synth.genome_ctgs(lengths, piece, first_chr_index=500 if tag == "synth384" else 1)
-            ss = engine.SeqSet(eng, [c["seq"] for c in g])
-            plan = engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS, tile_windows=args.tile, **prm)
-            t_r = time.perf_counter()                      # time-based ramp here too: 20 launches are 0.15-1.4 ms
-            while (time.perf_counter() - t_r) * 1e3 < 30.0:
-                for _ in range(50):
-                    plan.run()
-                eng.sync()
-            reps = 200 if tag == "S288c" else 40
-            eng.timer_start()
-            for _ in range(reps):
-                plan.run()
-            ms = eng.timer_stop() / reps
-            nw = plan.total_windows
-            e = {"workload": f"{sum(len(c['seq']) for c in g)} bp, {len(g)} ctgs, piece {piece}",
-                 "windows_per_launch": int(nw), "launch_ms": ms, "windows_per_s": nw / (ms * 1e-3),
-                 "achieved_GBps": nw * prm["step"] / (ms * 1e-3) / 1e9,
-                 "frac_of_8TBps": nw * prm["step"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-            if depth > 1:
-                plan.set_depth(depth)
-                plan.run_n(2000)
-                eng.sync()
-                t0 = time.perf_counter()
-                plan.run_n(1000)
-                eng.sync()
-                e["windows_per_s_4_in_flight"] = nw * 1000 / (time.perf_counter() - t0)
-            extra[tag] = e
-            plan.close()
-            if tag == "synth384" and prm["step"] != 1:
-                # SURVEY 8(d)'s secondary figure, configs[3]'s geometry (size 100 / step 1) on the same resident bytes:
-                # compute bound (1 B per window), a tile per wave
-                p1 = engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS, **dict(prm, step=1))
-                for _ in range(20):
-                    p1.run()
-                eng.sync()
+        try:
+            # (a) BASELINE configs[1]: the 12-Mb genome lives in L2/MALL and one launch lasts microseconds
+            #     (launch-latency bound); (b) a 384-Mb genome, one launch beyond the Infinity Cache.
+            for tag, lengths, piece, depth in (("S288c", synth.S288C_LENGTHS, 500000, 4),
+                                               ("synth384", synth.SYNTH384_LENGTHS, 1000000, 1)):
+                if tag == args.workload:
+                    continue
+                g = synth.genome_ctgs(lengths, piece, first_chr_index=500 if tag == "synth384" else 1)
+                ss = engine.SeqSet(eng, [c["seq"] for c in g])
+                plan = engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS, tile_windows=args.tile, **prm)
+                t_r = time.perf_counter()                      # time-based ramp here too: 20 launches are 0.15-1.4 ms
+                while (time.perf_counter() - t_r) * 1e3 < 30.0:
+                    for _ in range(50):
+                        plan.run()
+                    eng.sync()
+                reps = 200 if tag == "S288c" else 40
                 eng.timer_start()
-                for _ in range(20):
-                    p1.run()
-                ms1 = eng.timer_stop() / 20
-                extra["synth384_step1"] = {"workload": e["workload"] + ", size 100 step 1", "kernel": p1.kernel_name(),
-                                           "windows_per_launch": int(p1.total_windows), "launch_ms": ms1,
-                                           "windows_per_s": p1.total_windows / (ms1 * 1e-3),
-                                           "bytes_per_window": 1, "peaks": int(p1.peaks_count())}
-                p1.close()
-            ss.close()
-        # --influence other than 1 (stat.rs:42: a recurrence per ctg; guess-and-iterate on the device): ms per pass over the
-        # 59 ctgs of one 30-Mb chromosome, a reader waiting for the fixed point, and how the pass settled
-        if prm["step"] == 10:
-            c30 = synth.gen_ctgs("1", synth.chromosome(30_427_671, 1), piece=500000)
-            ss = engine.SeqSet(eng, [c["seq"] for c in c30])
-            infl = {}
-            for tag, influence, thr in (("influence_0.5", 0.5, 3.0), ("influence_0", 0.0, 3.0), ("influence_0_threshold_2", 0.0, 2.0)):
-                pl = engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS, **dict(prm, influence=influence, threshold=thr))
-                for _ in range(3):
-                    pl.run()
-                    pl.peaks_count()
-                eng.sync()
-                t0 = time.perf_counter()
-                for _ in range(10):
-                    pl.run()
-                    n_pk = pl.peaks_count()
-                eng.sync()
-                ms_i = (time.perf_counter() - t0) / 10 * 1e3
-                sweeps, serial = pl.settled()
-                infl[tag] = {"ms_per_pass": ms_i, "windows_per_s": pl.total_windows / (ms_i * 1e-3), "peaks": int(n_pk),
-                             "sweeps_queued": sweeps, "serial_fallback": bool(serial)}
-                pl.close()
-            infl["workload"] = f"{sum(len(c['seq']) for c in c30)} bp, {len(c30)} ctgs: pass + packed peaks in host memory"
-            extra["influence_30Mb"] = infl
-            ss.close()
+                for _ in range(reps):
+                    plan.run()
+                ms = eng.timer_stop() / reps
+                nw = plan.total_windows
+                e = {"workload": f"{sum(len(c['seq']) for c in g)} bp, {len(g)} ctgs, piece {piece}",
+                     "windows_per_launch": int(nw), "launch_ms": ms, "windows_per_s": nw / (ms * 1e-3),
+                     "achieved_GBps": nw * prm["step"] / (ms * 1e-3) / 1e9,
+                     "frac_of_8TBps": nw * prm["step"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                if depth > 1:
+                    plan.set_depth(depth)
+                    plan.run_n(2000)
+                    eng.sync()
+                    t0 = time.perf_counter()
+                    plan.run_n(1000)
+                    eng.sync()
+                    e["windows_per_s_4_in_flight"] = nw * 1000 / (time.perf_counter() - t0)
+                extra[tag] = e
+                plan.close()
+                if tag == "synth384" and prm["step"] != 1:
+                    # SURVEY 8(d)'s secondary figure, configs[3]'s geometry (size 100 / step 1) on the same resident bytes:
+                    # compute bound (1 B per window), a tile per wave
+                    p1 = engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS, **dict(prm, step=1))
+                    for _ in range(20):
+                        p1.run()
+                    eng.sync()
+                    eng.timer_start()
+                    for _ in range(20):
+                        p1.run()
+                    ms1 = eng.timer_stop() / 20
+                    extra["synth384_step1"] = {"workload": e["workload"] + ", size 100 step 1", "kernel": p1.kernel_name(),
+                                               "windows_per_launch": int(p1.total_windows), "launch_ms": ms1,
+                                               "windows_per_s": p1.total_windows / (ms1 * 1e-3),
+                                               "bytes_per_window": 1, "peaks": int(p1.peaks_count())}
+                    p1.close()
+                ss.close()
+            # --influence other than 1 (stat.rs:42: a recurrence per ctg; guess-and-iterate on the device): ms per pass over the
+            # 59 ctgs of one 30-Mb chromosome, a reader waiting for the fixed point, and how the pass settled
+            if prm["step"] == 10:
+                c30 = synth.gen_ctgs("1", synth.chromosome(30_427_671, 1), piece=500000)
+                ss = engine.SeqSet(eng, [c["seq"] for c in c30])
+                infl = {}
+                for tag, influence, thr in (("influence_0.5", 0.5, 3.0), ("influence_0", 0.0, 3.0), ("influence_0_threshold_2", 0.0, 2.0)):
+                    pl = engine.WavePlan(eng, ss, flags=_lib.WAVE_PEAKS, **dict(prm, influence=influence, threshold=thr))
+                    for _ in range(3):
+                        pl.run()
+                        pl.peaks_count()
+                    eng.sync()
+                    t0 = time.perf_counter()
+                    for _ in range(10):
+                        pl.run()
+                        n_pk = pl.peaks_count()
+                    eng.sync()
+                    ms_i = (time.perf_counter() - t0) / 10 * 1e3
+                    sweeps, serial = pl.settled()
+                    infl[tag] = {"ms_per_pass": ms_i, "windows_per_s": pl.total_windows / (ms_i * 1e-3), "peaks": int(n_pk),
+                                 "sweeps_queued": sweeps, "serial_fallback": bool(serial)}
+                    pl.close()
+                infl["workload"] = f"{sum(len(c['seq']) for c in c30)} bp, {len(c30)} ctgs: pass + packed peaks in host memory"
+                extra["influence_30Mb"] = infl
+                ss.close()
+        except Exception as e:  # noqa: BLE001
+            extra["error"] = f"{type(e).__name__}: {e}"
         out["extra"] = extra
     if rank == 0 and world == 1 and not args.no_secondary:
-        out["secondary"] = secondary_metrics(eng)
+        try:
+            out["secondary"] = secondary_metrics(eng)
+        except Exception as e:  # noqa: BLE001
+            out["secondary"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         emit(out)
     eng.close()
