@@ -67,6 +67,28 @@ int gams_ref_wave_rows(const char *chr, int32_t chr_start, const uint8_t *seq, u
     return GAMS_OK;
 }
 
+int gams_ref_wave_signal_text(const char *chr, int32_t chr_start, const uint8_t *seq, uint32_t len,
+                              const gams_wave_params_t *p, char **text, uint64_t *text_bytes) {
+    if (!chr || !seq || !p || !text || !text_bytes) return GAMS_EINVAL;
+    char *t = ora_wave_proc_ctg(chr, chr_start, chr_start + (int32_t)len - 1, seq, p->size, p->step, p->lag,
+                                p->threshold, p->influence, 0.2f, 1);         /* wave.rs:158-168 */
+    if (!t) return GAMS_ESHORT;
+    *text = t;
+    *text_bytes = strlen(t);
+    return GAMS_OK;
+}
+
+int gams_ref_sw_text(const char *chr, const uint8_t *seq, uint32_t len, int32_t chr_start, const int32_t *fs,
+                     const int32_t *fe, const char *const *fid, uint32_t nf, int32_t size, int32_t max, int32_t resize,
+                     char **text, uint64_t *text_bytes) {
+    if (!chr || !seq || !text || !text_bytes || (nf && (!fs || !fe || !fid))) return GAMS_EINVAL;
+    char *t = ora_sw_proc_ctg(chr, chr_start, chr_start + (int32_t)len - 1, seq, fid, fs, fe, nf, size, max, resize);  /* sw.rs:108-194 */
+    if (!t) return GAMS_ENOMEM;
+    *text = t;
+    *text_bytes = strlen(t);
+    return GAMS_OK;
+}
+
 int gams_ref_sw(const uint8_t *seq, uint32_t len, int32_t chr_start, const int32_t *fs, const int32_t *fe, uint32_t nf,
                 int32_t size, int32_t max, int32_t resize, gams_sw_row_t *rows, uint64_t cap, uint64_t *n_rows) {
     if (!seq || !n_rows || (nf && (!fs || !fe))) return GAMS_EINVAL;

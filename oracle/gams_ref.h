@@ -28,6 +28,13 @@ int gams_ref_wave_peaks(uint32_t n_ctg, const uint8_t *const *seqs, const uint32
 /* gams_wave_rows_*: the TSV rows of one ctg (wave.rs:157-252); malloc'd, free with gams_ref_free */
 int gams_ref_wave_rows(const char *chr, int32_t chr_start, const uint8_t *seq, uint32_t len,
                        const gams_wave_params_t *params, float coverage, char **text, uint64_t *text_bytes);
+/* gams_wave_signal_text: the `--signal` rows of one ctg, a row per window (wave.rs:158-168); malloc'd */
+int gams_ref_wave_signal_text(const char *chr, int32_t chr_start, const uint8_t *seq, uint32_t len,
+                              const gams_wave_params_t *params, char **text, uint64_t *text_bytes);
+/* gams_gpu_sw_text for one ctg: the rows as `Sw`'s Display prints them (sw.rs:152-190, data.rs:58-83); malloc'd */
+int gams_ref_sw_text(const char *chr, const uint8_t *seq, uint32_t len, int32_t chr_start, const int32_t *feat_start,
+                     const int32_t *feat_end, const char *const *feat_id, uint32_t nf, int32_t size, int32_t max,
+                     int32_t resize, char **text, uint64_t *text_bytes);
 /* gams_gpu_sw for one ctg whose first base sits at chr_start (sw.rs:141-184) */
 int gams_ref_sw(const uint8_t *seq, uint32_t len, int32_t chr_start, const int32_t *feat_start,
                 const int32_t *feat_end, uint32_t nf, int32_t size, int32_t max, int32_t resize,

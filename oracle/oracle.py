@@ -284,6 +284,11 @@ def ref():
     L.gams_ref_wave_rows.restype = C.c_int
     L.gams_ref_wave_rows.argtypes = [C.c_char_p, C.c_int32, VP, C.c_uint32, C.POINTER(WaveParams), C.c_float,
                                      C.POINTER(C.c_void_p), U64P]
+    L.gams_ref_wave_signal_text.restype = C.c_int
+    L.gams_ref_wave_signal_text.argtypes = [C.c_char_p, C.c_int32, VP, C.c_uint32, C.POINTER(WaveParams), C.POINTER(C.c_void_p), U64P]
+    L.gams_ref_sw_text.restype = C.c_int
+    L.gams_ref_sw_text.argtypes = [C.c_char_p, VP, C.c_uint32, C.c_int32, VP, VP, C.POINTER(C.c_char_p), C.c_uint32, C.c_int32,
+                                   C.c_int32, C.c_int32, C.POINTER(C.c_void_p), U64P]
     L.gams_ref_sw.restype = C.c_int
     L.gams_ref_sw.argtypes = [VP, C.c_uint32, C.c_int32, VP, VP, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, VP,
                               C.c_uint64, U64P]

@@ -55,8 +55,9 @@ def test_twin_signatures_follow_the_header():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ref_h = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "oracle", "gams_ref.h")).read(), flags=re.S)
     twins = dict(re.findall(r"int (gams_ref_[a-z_]+)\(([^;]*?)\);", ref_h, flags=re.S))
-    assert set(twins) == {"gams_ref_wave", "gams_ref_wave_peaks", "gams_ref_wave_rows", "gams_ref_sw", "gams_ref_range_gc",
-                          "gams_ref_count", "gams_ref_locate", "gams_ref_cover", "gams_ref_valid_spans"}
+    assert set(twins) == {"gams_ref_wave", "gams_ref_wave_peaks", "gams_ref_wave_rows", "gams_ref_wave_signal_text", "gams_ref_sw",
+                          "gams_ref_sw_text", "gams_ref_range_gc", "gams_ref_count", "gams_ref_locate", "gams_ref_cover",
+                          "gams_ref_valid_spans"}
     abi_h = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "gams_gpu.h")).read(), flags=re.S)
     abi = dict(re.findall(r"int (gams_gpu_[a-z_]+)\(([^;]*?)\);", abi_h, flags=re.S))
 
@@ -121,6 +122,17 @@ def test_wave_entries_equal_their_twins(eng, s288c):
                 assert text[int(off[c]):int(off[c + 1])] == C.string_at(txt.value, nb_.value)
                 R.gams_ref_free(txt)
         plan.close()
+        # ... and the --signal rows of every window (plans with the dense rows)
+        plan = engine.WavePlan(eng, ss, p.size, p.step, p.lag, p.threshold, p.influence, flags=_lib.WAVE_DENSE)
+        plan.run()
+        text, off = plan.signal_text(["I", "Mito"], [1, 5])
+        for c, (name, cs) in enumerate((("I", 1), ("Mito", 5))):
+            txt, nb_ = C.c_void_p(), C.c_uint64()
+            assert R.gams_ref_wave_signal_text(name.encode(), cs, seqs[c].ctypes.data, seqs[c].size, C.byref(p), C.byref(txt),
+                                               C.byref(nb_)) == 0
+            assert text[int(off[c]):int(off[c + 1])] == C.string_at(txt.value, nb_.value)
+            R.gams_ref_free(txt)
+        plan.close()
         ss.close()
 
 
@@ -143,6 +155,19 @@ def test_sw_range_gc_and_gen_equal_their_twins(eng, s288c):
                          b_rows.ctypes.data, cap, C.byref(nb)) == 0
     assert na.value == nb.value > 0
     assert a_rows[:na.value].tobytes() == b_rows[:nb.value].tobytes()          # every field, floats bit for bit
+    # the same rows as text: gams_gpu_sw_text against its twin
+    ids = [f"feature:ctg:I:1:{j + 1}".encode() for j in range(fs.size)]
+    id_arr = (C.c_char_p * fs.size)(*ids)
+    chr_arr = (C.c_char_p * 1)(b"I")
+    sel, cst, foff = np.zeros(1, np.uint32), np.array([chr_start], np.int32), np.array([0, fs.size], np.uint64)
+    txt, tb, toff, nr = C.c_void_p(), C.c_uint64(), C.c_void_p(), C.c_uint64()
+    eng.check(eng.lib.gams_gpu_sw_text(eng.h, ss.p, 1, sel.ctypes.data, chr_arr, cst.ctypes.data, foff.ctypes.data, fs.ctypes.data,
+                                       fe.ctypes.data, id_arr, 100, 20, 500, C.byref(txt), C.byref(tb), C.byref(toff), C.byref(nr)))
+    rt, rb = C.c_void_p(), C.c_uint64()
+    assert R.gams_ref_sw_text(b"I", seq.ctypes.data, seq.size, chr_start, fs.ctypes.data, fe.ctypes.data, id_arr, fs.size, 100, 20,
+                              500, C.byref(rt), C.byref(rb)) == 0
+    assert nr.value == na.value and C.string_at(txt.value, tb.value) == C.string_at(rt.value, rb.value)
+    R.gams_ref_free(rt)
     rs = rng.integers(chr_start, chr_start + seq.size - 2000, 500).astype(np.int32)
     re_ = (rs + rng.integers(0, 1999, rs.size)).astype(np.int32)
     a_gc, b_gc = np.zeros(rs.size, np.float32), np.zeros(rs.size, np.float32)
